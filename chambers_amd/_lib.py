@@ -1,0 +1,121 @@
+"""ctypes binding of libchambers_hip.so (the C ABI declared in include/chambers_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call returns an
+error code, an exception is raised.  torch is imported first so that the HIP runtime the
+library links against (libamdhip64.so.7) is the instance torch already loaded — streams and
+device pointers are then shared between torch (allocation / streams / RCCL) and the kernels.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares libamdhip64 with torch)
+
+from . import _build
+
+c_void_p, c_int, c_int64, c_float, c_uint32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
+
+CHB_OK, CHB_EINVAL, CHB_ELAUNCH, CHB_EUNSUPPORTED = 0, -1, -2, -3
+
+PW_INVERT, PW_POSTERIZE, PW_SOLARIZE, PW_SOLARIZE_ADD, PW_BRIGHTNESS, PW_CONTRAST, PW_COLOR = range(7)
+NORM_CAFFE, NORM_TF, NORM_TORCH = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_PATCH = range(5)
+OUT_BF16, OUT_F32 = 0, 1
+
+P = c_void_p
+# name -> argument ctypes (all return int except the two info calls)
+PROTOTYPES = {
+    "chb_aug_pointwise": [P, P, c_int64, c_int, c_float, c_int, c_int, P],
+    "chb_aug_affine": [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P],
+    "chb_aug_cutout": [P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
+    "chb_aug_autocontrast": [P, P, c_int, c_int, c_int, c_int, P, P],
+    "chb_aug_equalize": [P, P, c_int, c_int, c_int, c_int, P, P],
+    "chb_aug_sharpness": [P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "chb_normalize_u8": [P, P, c_int64, c_int, c_int, P],
+    "chb_normalize_f32": [P, P, c_int64, c_int, c_int, P],
+    "chb_normalize_patchify_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "chb_patchify_f32_bf16": [P, P, c_int, c_int, c_int, c_int, P],
+    "chb_dropout_mask": [P, c_int64, c_float, c_uint32, P],
+    "chb_gemm_nt": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P, c_int, c_int, P, c_int64, P, c_int64,
+                    c_int, c_float, c_uint32, P],
+    "chb_gemm_tn": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P],
+    "chb_layernorm_fwd": [P, c_int64, P, P, P, P, P, c_int, c_int, c_float, P],
+    "chb_layernorm_bwd": [P, P, c_int64, P, P, P, P, c_int64, c_int, P, P, c_int, c_int, P],
+    "chb_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P],
+    "chb_attention_bwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P],
+    "chb_cls_row": [P, P, P, c_int, c_int, c_int, c_float, c_uint32, P],
+    "chb_embed_bwd": [P, P, P, P, c_int, c_int, c_int, c_float, c_uint32, P],
+    "chb_dropout_bwd_bf16": [P, c_int64, P, c_int, c_int, c_float, c_uint32, P],
+    "chb_colsum_bf16": [P, c_int64, P, c_int, c_int, P],
+    "chb_softmax_ce": [P, c_int64, P, P, P, c_int64, c_int, c_int, c_float, P],
+    "chb_cast_transpose": [P, P, P, P, c_int, c_int, P],
+    "chb_adamw": [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P],
+}
+INFO_SYMBOLS = ["chb_version", "chb_build_arch"]
+
+_lib = None
+
+
+class ChambersHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ChambersHipError(
+            "libchambers_hip.so not found at %s — run `python -m chambers_amd._build` "
+            "(or __graft_entry__.build()); there is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.chb_version.restype = c_int
+    lib.chb_build_arch.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+_ERR = {CHB_EINVAL: "invalid argument", CHB_ELAUNCH: "kernel launch failed", CHB_EUNSUPPORTED: "unsupported shape"}
+
+
+def check(name, code):
+    """Map C-ABI return codes onto the reference's Python error conventions."""
+    if code == CHB_OK:
+        return
+    msg = "%s: %s (code %d)" % (name, _ERR.get(code, "error"), code)
+    if code in (CHB_EINVAL, CHB_EUNSUPPORTED):
+        raise ValueError(msg)
+    raise ChambersHipError(msg)
+
+
+def stream_ptr():
+    """Current torch HIP stream as a raw hipStream_t."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise ChambersHipError(
+                "chambers_amd kernels run on an MI355X only; got a %s tensor (no CPU fallback)" % t.device)
+
+
+def call(name, *args):
+    lib = load()
+    check(name, getattr(lib, name)(*args))

@@ -1,0 +1,405 @@
+// Fused multi-head attention forward/backward for ViT sequence lengths (N = 197 / 577), gfx950.
+//
+// One workgroup (4 waves) owns one (image, head).  N is small enough that the head's K and V
+// (and in the backward Q and dO too) stay resident in LDS, so scores never touch HBM:
+//   forward : S^T = K.Q^T (keys on MFMA rows -> a lane holds ONE query's scores, softmax is an
+//             in-lane reduction + 2 shuffles), P^T feeds the P.V MFMA straight from the
+//             accumulators (k-order permuted on both operands), V^T via ds_read_b64_tr_b16.
+//   backward: each wave owns 1/4 of the key tiles and keeps dK^T/dV^T for them in registers
+//             across all query blocks; dS goes once through LDS for dQ.  No atomics.
+// Dropout on the probabilities uses the counter hash of common.hpp, element index
+// ((b*H + h)*N + q)*N + k, so forward and backward regenerate the same mask.
+//
+// Replaces keras Attention under chambers' ScaledAttention / MultiHeadAttention:
+// layers/attention.py:13-23 (scores / sqrt(head_dim) after the matmul), :120-125.
+#include "common.hpp"
+#include "../../include/chambers_hip.h"
+
+namespace {
+
+constexpr int HD = 64;  // head dim (all ViT configs of the reference use 64)
+
+__device__ __forceinline__ int swz_row(int r) { return (r >> 1) & 7; }          // row reads (ds_read_b128)
+__device__ __forceinline__ int swz_trv(int r) { return ((r >> 1) & 3) << 1; }   // V image, transposed reads only
+
+// row fragment: 8 consecutive d of row r, chunk index `chunk` (0..7), image swizzled with swz_row
+__device__ __forceinline__ bf16x8_t lds_row_frag(const bf16_t* img, int r, int chunk) {
+    return *reinterpret_cast<const bf16x8_t*>(img + r * HD + ((chunk ^ swz_row(r)) << 3));
+}
+
+// transposed fragment for MFMA lane (g, i): element j<4 = img[ra + j'][c0 + i], j>=4 = img[rb + j'][c0 + i],
+// where this lane supplies the addresses of rows ra + (i>>2) / rb + (i>>2), columns c0 + 4*(i&3).
+template <bool VSWZ>
+__device__ __forceinline__ bf16x8_t lds_tr_frag(const bf16_t* img, int ra, int rb, int c0, int i) {
+    const int q = i >> 2, pp = i & 3;
+    const int chunk = (c0 >> 3) + (pp >> 1);
+    const int r0 = ra + q, r1 = rb + q;
+    const int s0 = VSWZ ? swz_trv(r0) : swz_row(r0);
+    const int s1 = VSWZ ? swz_trv(r1) : swz_row(r1);
+    const bf16_t* a0 = img + r0 * HD + ((chunk ^ s0) << 3) + 4 * (pp & 1);
+    const bf16_t* a1 = img + r1 * HD + ((chunk ^ s1) << 3) + 4 * (pp & 1);
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a0);
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a1);
+    short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const float4_t& a, const float4_t& b) {
+    short8_t v;
+    v[0] = (short)f32_to_bf16(a[0]); v[1] = (short)f32_to_bf16(a[1]); v[2] = (short)f32_to_bf16(a[2]); v[3] = (short)f32_to_bf16(a[3]);
+    v[4] = (short)f32_to_bf16(b[0]); v[5] = (short)f32_to_bf16(b[1]); v[6] = (short)f32_to_bf16(b[2]); v[7] = (short)f32_to_bf16(b[3]);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// stage rows [0, nrows_pad) x 64 of one head slice into an LDS image (zero rows >= n_valid)
+template <bool VSWZ>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64_t row_stride, int n_valid, int nrows_pad,
+                                           bf16_t* img, int tid) {
+    for (int id = tid; id < nrows_pad * 8; id += 256) {
+        const int r = id >> 3, c = id & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < n_valid) v = *reinterpret_cast<const uint4*>(src + (int64_t)r * row_stride + c * 8);
+        const int s = VSWZ ? swz_trv(r) : swz_row(r);
+        *reinterpret_cast<uint4*>(img + r * HD + ((c ^ s) << 3)) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int NTP>  // pairs of 16-key tiles; padded key count = 32 * NTP
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse_out,
+                                                       int N, int H, float scale_log2, float drop_scale, uint32_t drop_thr,
+                                                       uint32_t drop_key) {
+    constexpr int NKP = 32 * NTP, NT = 2 * NTP;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[NKP * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[NKP * HD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const bf16_t* base = qkv + (int64_t)b * N * D3 + h * HD;
+
+    stage_rows<false>(base + Dm, D3, N, NKP, Ks, tid);
+    stage_rows<true>(base + 2 * Dm, D3, N, NKP, Vs, tid);
+    __syncthreads();
+
+    const int nqt = (N + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q0 = qt * 16;
+        const int qrow = min(q0 + i, N - 1);  // clamp: pad queries recompute a valid row, never stored
+        const bf16_t* qp = base + (int64_t)qrow * D3;
+        const bf16x8_t qf0 = *reinterpret_cast<const bf16x8_t*>(qp + g * 8);
+        const bf16x8_t qf1 = *reinterpret_cast<const bf16x8_t*>(qp + 32 + g * 8);
+
+        float4_t s[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, g), qf0, s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 + g), qf1, s[t], 0, 0, 0);
+        }
+        // lane (g,i): s[t][r] = score(query q0+i, key 16t + 4g + r)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * g + r;
+                s[t][r] = key < N ? s[t][r] * scale_log2 : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][r] = exp2f(s[t][r] - mx);
+                sum += s[t][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        const int q = q0 + i;
+        if (g == 0 && q < N) lse_out[(int64_t)bh * N + q] = (mx + log2f(sum)) * 0.69314718055994530942f;
+        const uint64_t ebase = ((uint64_t)bh * (uint64_t)N + (uint64_t)min(q, N - 1)) * (uint64_t)N;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (drop_thr) {
+                const uint64_t e0 = ebase + (uint64_t)(16 * t + 4 * g);
+                const uint32_t c0 = (uint32_t)(e0 >> 1), odd = (uint32_t)(e0 & 1);
+                const uint32_t h0 = chb_hash32(c0 ^ drop_key), h1 = chb_hash32((c0 + 1u) ^ drop_key), h2 = chb_hash32((c0 + 2u) ^ drop_key);
+                // element e0 + r uses 16-bit half ((odd + r) & 1) of hash (odd + r) >> 1
+                const uint32_t ue[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+                const uint32_t uo[4] = {h0 >> 16, h1 & 0xffffu, h1 >> 16, h2 & 0xffffu};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t u = odd ? uo[r] : ue[r];
+                    s[t][r] = (u >= drop_thr) ? s[t][r] * inv * drop_scale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] *= inv;
+            }
+        }
+        // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; k-slot (g, j): j<4 -> key 32u+4g+j, j>=4 -> key 32u+16+4g+(j-4)
+        float4_t oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NTP; ++u) {
+            const bf16x8_t pf = pack8(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t vf = lds_tr_frag<true>(Vs, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, i);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+        if (q < N) {
+            bf16_t* op = o + ((int64_t)b * N + q) * Dm + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 w;
+                w.x = pack_bf16x2(oacc[dt][0], oacc[dt][1]);
+                w.y = pack_bf16x2(oacc[dt][2], oacc[dt][3]);
+                *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward
+// LDS: K, V, Q, dO images [NP][64] (row-read swizzle; transposed reads take a 2-way conflict),
+// dS double buffer [2][32][NP + 8], lse*log2e and delta per query.
+template <int NTP>
+__global__ void __launch_bounds__(256) attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+                                                       const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, float scale,
+                                                       float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key) {
+    constexpr int NP = 32 * NTP, NT = 2 * NTP;
+    constexpr int MT = (NT + 3) / 4;   // key tiles owned by one wave (wave w: tiles w, w+4, ...)
+    constexpr int DSLD = NP + 8;       // dS row stride (elements)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Vs = Ks + NP * HD;
+    bf16_t* Qs = Vs + NP * HD;
+    bf16_t* Gs = Qs + NP * HD;                      // dO
+    bf16_t* dSs = Gs + NP * HD;                     // [2][32][DSLD]
+    float* lse2 = reinterpret_cast<float*>(dSs + 2 * 32 * DSLD);
+    float* delta = lse2 + NP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const bf16_t* base = qkv + (int64_t)b * N * D3 + h * HD;
+    const bf16_t* obase = o + (int64_t)b * N * Dm + h * HD;
+    const bf16_t* gbase = d_o + (int64_t)b * N * Dm + h * HD;
+
+    stage_rows<false>(base, D3, N, NP, Qs, tid);
+    stage_rows<false>(base + Dm, D3, N, NP, Ks, tid);
+    stage_rows<false>(base + 2 * Dm, D3, N, NP, Vs, tid);
+    // dO image + delta[q] = sum_d dO*O (8 threads per row, one 16-byte chunk each)
+    for (int id = tid; id < NP * 8; id += 256) {
+        const int r = id >> 3, c = id & 7;
+        uint4 gv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+        if (r < N) {
+            gv = *reinterpret_cast<const uint4*>(gbase + (int64_t)r * Dm + c * 8);
+            ov = *reinterpret_cast<const uint4*>(obase + (int64_t)r * Dm + c * 8);
+        }
+        *reinterpret_cast<uint4*>(Gs + r * HD + ((c ^ swz_row(r)) << 3)) = gv;
+        const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d += bf16_to_f32((bf16_t)(gw[k] & 0xffff)) * bf16_to_f32((bf16_t)(ow[k] & 0xffff));
+            d += bf16_to_f32((bf16_t)(gw[k] >> 16)) * bf16_to_f32((bf16_t)(ow[k] >> 16));
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (c == 0) delta[r] = d;
+    }
+    for (int r = tid; r < NP; r += 256) lse2[r] = r < N ? lse[(int64_t)bh * N + r] * 1.44269504088896340736f : INFINITY;
+    __syncthreads();
+
+    float4_t dk[4][MT], dv[4][MT];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+            dk[dt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            dv[dt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+
+    for (int it = 0; it < NTP; ++it) {
+        const int q0 = 32 * it;
+        bf16_t* dSb = dSs + (it & 1) * 32 * DSLD;
+        // ---- phase A: this wave's key tiles against the 32 queries of the block
+        bf16x8_t qa[2][2], ga[2][2];  // [query sub-tile][k-step]: A operands, rows = queries
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                qa[qs][ks] = lds_row_frag(Qs, q0 + 16 * qs + i, 4 * ks + g);
+                ga[qs][ks] = lds_row_frag(Gs, q0 + 16 * qs + i, 4 * ks + g);
+            }
+        float l2[2][4], dl[2][4];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                l2[qs][r] = lse2[q0 + 16 * qs + 4 * g + r];
+                dl[qs][r] = delta[q0 + 16 * qs + 4 * g + r];
+            }
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+            const int t = wave + 4 * c;
+            if (t < NT) {  // wave-uniform
+                const int key = 16 * t + i;
+                float4_t pd[2], ds[2];
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    float4_t sv = (float4_t){0.f, 0.f, 0.f, 0.f}, dp = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        // D[row = query 4g+r][col = key i]
+                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qs][ks], lds_row_frag(Ks, 16 * t + i, 4 * ks + g), sv, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[qs][ks], lds_row_frag(Vs, 16 * t + i, 4 * ks + g), dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = q0 + 16 * qs + 4 * g + r;
+                        float p = (key < N) ? exp2f(sv[r] * scale_log2 - l2[qs][r]) : 0.f;
+                        float keepc = 1.0f;
+                        if (drop_thr) {
+                            const uint64_t e = ((uint64_t)bh * (uint64_t)N + (uint64_t)min(q, N - 1)) * (uint64_t)N + (uint64_t)min(key, N - 1);
+                            keepc = chb_keep(e, drop_key, drop_thr) ? drop_scale : 0.f;
+                        }
+                        pd[qs][r] = p * keepc;                                   // dropped probabilities (for dV)
+                        ds[qs][r] = p * (dp[r] * keepc - dl[qs][r]) * scale;     // d(scores) incl. 1/sqrt(hd)
+                    }
+                }
+                // contraction over the 32 queries: k-slot (g, j): j<4 -> q0+4g+j, j>=4 -> q0+16+4g+(j-4)
+                const bf16x8_t pf = pack8(pd[0], pd[1]);
+                const bf16x8_t sf = pack8(ds[0], ds[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8_t gt = lds_tr_frag<false>(Gs, q0 + 4 * g, q0 + 16 + 4 * g, 16 * dt, i);
+                    const bf16x8_t qt = lds_tr_frag<false>(Qs, q0 + 4 * g, q0 + 16 + 4 * g, 16 * dt, i);
+                    dv[dt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dv[dt][c], 0, 0, 0);  // dV^T[d][key]
+                    dk[dt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sf, dk[dt][c], 0, 0, 0);  // dK^T[d][key]
+                }
+                // dS tile -> LDS [query][key] for the dQ product
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dSb[(16 * qs + 4 * g + r) * DSLD + key] = f32_to_bf16(ds[qs][r]);
+            }
+        }
+        __syncthreads();
+        // ---- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; wave w owns d-tile w
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float4_t dq = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NTP; ++u) {
+                const bf16x8_t kt = lds_tr_frag<false>(Ks, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * wave, i);  // A[row d][k = key 32u+8g+j]
+                const bf16x8_t sb = *reinterpret_cast<const bf16x8_t*>(dSb + (16 * qs + i) * DSLD + 32 * u + 8 * g);  // B[k][col q]
+                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, sb, dq, 0, 0, 0);
+            }
+            const int q = q0 + 16 * qs + i;
+            if (q < N) {
+                uint2 w;
+                w.x = pack_bf16x2(dq[0], dq[1]);
+                w.y = pack_bf16x2(dq[2], dq[3]);
+                *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * wave + 4 * g) = w;
+            }
+        }
+    }
+    // dK^T / dV^T accumulators: lane (g,i) reg r = [d = 16dt + 4g + r][key = 16t + i]
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+        const int t = wave + 4 * c;
+        const int key = 16 * t + i;
+        if (t < NT && key < N) {
+            bf16_t* kp = dqkv + ((int64_t)b * N + key) * D3 + Dm + h * HD;
+            bf16_t* vp = kp + Dm;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 w;
+                w.x = pack_bf16x2(dk[dt][c][0], dk[dt][c][1]);
+                w.y = pack_bf16x2(dk[dt][c][2], dk[dt][c][3]);
+                *reinterpret_cast<uint2*>(kp + 16 * dt + 4 * g) = w;
+                w.x = pack_bf16x2(dv[dt][c][0], dv[dt][c][1]);
+                w.y = pack_bf16x2(dv[dt][c][2], dv[dt][c][3]);
+                *reinterpret_cast<uint2*>(vp + 16 * dt + 4 * g) = w;
+            }
+        }
+    }
+}
+
+template <int NTP>
+constexpr size_t bwd_lds_bytes() {
+    return (size_t)(4 * 32 * NTP * HD + 2 * 32 * (32 * NTP + 8)) * sizeof(bf16_t) + (size_t)2 * 32 * NTP * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" {
+
+int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate, uint32_t drop_key,
+                      void* stream) {
+    if (!qkv || !o || !lse || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
+    if (hd != HD || N > 608) return CHB_EUNSUPPORTED;
+    if (B == 0) return CHB_OK;
+    const float scale_log2 = 1.44269504088896340736f / sqrtf((float)hd);
+    const float ds = 1.0f / (1.0f - drop_rate);
+    const uint32_t thr = drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u;
+    const dim3 grid(B * H), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bf16_t* in = (const bf16_t*)qkv;
+    bf16_t* out = (bf16_t*)o;
+#define CHB_FWD(NTP) hipLaunchKernelGGL(attn_fwd_kernel<NTP>, grid, block, 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key)
+    if (N <= 32) CHB_FWD(1);
+    else if (N <= 64) CHB_FWD(2);
+    else if (N <= 128) CHB_FWD(4);
+    else if (N <= 224) CHB_FWD(7);
+    else if (N <= 416) CHB_FWD(13);
+    else CHB_FWD(19);
+#undef CHB_FWD
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N, int H, int hd,
+                      float drop_rate, uint32_t drop_key, void* stream) {
+    if (!qkv || !o || !d_o || !lse || !dqkv || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
+    if (hd != HD || N > 224) return CHB_EUNSUPPORTED;  // backward keeps Q,K,V,dO of a head in LDS
+    if (B == 0) return CHB_OK;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float scale_log2 = 1.44269504088896340736f * scale;
+    const float ds = 1.0f / (1.0f - drop_rate);
+    const uint32_t thr = drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u;
+    const dim3 grid(B * H), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define CHB_BWD(NTP)                                                                                                             \
+    do {                                                                                                                         \
+        const size_t lds = bwd_lds_bytes<NTP>();                                                                                 \
+        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=      \
+            hipSuccess)                                                                                                          \
+            return CHB_ELAUNCH;                                                                                                  \
+        hipLaunchKernelGGL(attn_bwd_kernel<NTP>, grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
+                           lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key);                                      \
+    } while (0)
+    if (N <= 32) CHB_BWD(1);
+    else if (N <= 64) CHB_BWD(2);
+    else if (N <= 128) CHB_BWD(4);
+    else CHB_BWD(7);
+#undef CHB_BWD
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,756 @@
+// RandAugment / AutoAugment primitive ops on uint8 NHWC batches, gfx950.
+//
+// Every kernel here is HBM-bound byte work: one pass reads each input byte once and
+// writes each output byte once (two-pass ops read the input twice).  Threads own
+// 4 pixels = 12 contiguous bytes (global_load_dwordx3 / global_store_dwordx3), so a
+// wave touches 768 contiguous bytes per instruction and RGB triples never straddle
+// threads.  Compiled with -ffp-contract=off: the float-mediated ops must round after
+// every multiply and add exactly like the un-fused TF CPU kernels the oracle restates.
+//
+// Reference semantics: chambers/augmentations/image_augmentations.py (lines cited per
+// kernel); upstream TF / tensorflow-addons behaviour as restated in oracle/augment_ref.py.
+#include "common.hpp"
+#include "../../include/chambers_hip.h"
+
+namespace {
+
+struct __attribute__((packed, aligned(4))) px4_t { uint32_t w[3]; };
+
+__device__ __forceinline__ void unpack12(const px4_t& p, uint8_t (&b)[12]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        b[4 * i + 0] = p.w[i] & 0xff;
+        b[4 * i + 1] = (p.w[i] >> 8) & 0xff;
+        b[4 * i + 2] = (p.w[i] >> 16) & 0xff;
+        b[4 * i + 3] = (p.w[i] >> 24) & 0xff;
+    }
+}
+__device__ __forceinline__ px4_t pack12(const uint8_t (&b)[12]) {
+    px4_t p;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        p.w[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) |
+                 ((uint32_t)b[4 * i + 3] << 24);
+    return p;
+}
+
+// tf.cast(float -> uint8) of an in-range value: truncation
+__device__ __forceinline__ uint8_t trunc_u8(float v) { return (uint8_t)(int)v; }
+
+// blend(), image_augmentations.py:10-49, for factor not in {0, 1}
+template <bool CLIP>
+__device__ __forceinline__ uint8_t blend1(uint8_t deg, uint8_t x, float factor) {
+    const float i1 = (float)deg, i2 = (float)x;
+    const float diff = i2 - i1;
+    const float scaled = factor * diff;
+    float t = i1 + scaled;
+    if (CLIP) t = fminf(fmaxf(t, 0.0f), 255.0f);
+    return trunc_u8(t);
+}
+
+// tf.image.rgb_to_grayscale on uint8 (see oracle rgb_to_grayscale)
+__device__ __forceinline__ uint8_t gray_u8(uint8_t r, uint8_t g, uint8_t b) {
+    const float s = 1.0f / 255.0f;
+    float v = ((float)r * s) * 0.2989f;
+    v = v + ((float)g * s) * 0.5870f;
+    v = v + ((float)b * s) * 0.1140f;
+    v = v * 255.5f;
+    return trunc_u8(v);
+}
+
+struct PwParams {
+    int op;
+    float factor;
+    int i0, i1;
+};
+
+template <int OP>
+__device__ __forceinline__ void pointwise12(uint8_t (&b)[12], const PwParams& pp) {
+    if (OP == CHB_PW_INVERT) {  // :112-113
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b[i] = 255 - b[i];
+    } else if (OP == CHB_PW_POSTERIZE) {  // :171-174, i0 = shift
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b[i] = (uint8_t)((b[i] >> pp.i0) << pp.i0);
+    } else if (OP == CHB_PW_SOLARIZE) {  // :192-193, i0 = threshold
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b[i] = ((int)b[i] < pp.i0) ? b[i] : (uint8_t)(255 - b[i]);
+    } else if (OP == CHB_PW_SOLARIZE_ADD) {  // :212-215, i0 = threshold, i1 = addition
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            int v = (int)b[i] + pp.i1;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            b[i] = ((int)b[i] < pp.i0) ? (uint8_t)v : b[i];
+        }
+    } else if (OP == CHB_PW_BRIGHTNESS) {  // :283-285
+        const bool clip = !(pp.factor > 0.0f && pp.factor < 1.0f);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b[i] = clip ? blend1<true>(0, b[i], pp.factor) : blend1<false>(0, b[i], pp.factor);
+    } else if (OP == CHB_PW_CONTRAST) {  // :253-265, i0 = degenerate constant
+        const bool clip = !(pp.factor > 0.0f && pp.factor < 1.0f);
+        const uint8_t d = (uint8_t)pp.i0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b[i] = clip ? blend1<true>(d, b[i], pp.factor) : blend1<false>(d, b[i], pp.factor);
+    } else if (OP == CHB_PW_COLOR) {  // :233-235 (3 channels)
+        const bool clip = !(pp.factor > 0.0f && pp.factor < 1.0f);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint8_t d = gray_u8(b[3 * p], b[3 * p + 1], b[3 * p + 2]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                b[3 * p + c] = clip ? blend1<true>(d, b[3 * p + c], pp.factor) : blend1<false>(d, b[3 * p + c], pp.factor);
+        }
+    }
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) pointwise_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        int64_t n_groups, int64_t n_bytes, PwParams pp) {
+    const px4_t* in4 = reinterpret_cast<const px4_t*>(in);
+    px4_t* out4 = reinterpret_cast<px4_t*>(out);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
+        px4_t p = in4[g];
+        uint8_t b[12];
+        unpack12(p, b);
+        pointwise12<OP>(b, pp);
+        out4[g] = pack12(b);
+    }
+    // tail (< 12 bytes, whole pixels): one thread
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t base = n_groups * 12;
+        const int tail = (int)(n_bytes - base);
+        if (tail > 0) {
+            uint8_t b[12];
+            for (int i = 0; i < 12; ++i) b[i] = i < tail ? in[base + i] : 0;
+            pointwise12<OP>(b, pp);
+            for (int i = 0; i < tail; ++i) out[base + i] = b[i];
+        }
+    }
+}
+
+inline int stream_grid(int64_t n_groups) {
+    int64_t blocks = (n_groups + 255) / 256;
+    if (blocks > 8192) blocks = 8192;  // 256 CUs x 8 blocks x 4: grid-stride the rest
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ---- nearest-neighbour projective warp (tfa.image.transform), :333-341 etc. -----
+__global__ void __launch_bounds__(256) affine_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
+                                                     int W, int C, const float* __restrict__ tdev, int per_image,
+                                                     float t0, float t1, float t2, float t3, float t4, float t5,
+                                                     float t6, float t7, int fill) {
+    const int wq = (W + 3) >> 2;  // x-quads per row
+    const int64_t total = (int64_t)B * H * wq;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const int xq = (int)(q % wq);
+        const int64_t r = q / wq;
+        const int oy = (int)(r % H);
+        const int n = (int)(r / H);
+        float a0 = t0, a1 = t1, a2 = t2, b0 = t3, b1 = t4, b2 = t5, c0 = t6, c1 = t7;
+        if (tdev) {
+            const float* t = tdev + (per_image ? (int64_t)n * 8 : 0);
+            a0 = t[0]; a1 = t[1]; a2 = t[2]; b0 = t[3]; b1 = t[4]; b2 = t[5]; c0 = t[6]; c1 = t[7];
+        }
+        const uint8_t* img = in + (int64_t)n * H * W * C;
+        uint8_t* orow = out + ((int64_t)n * H + oy) * (int64_t)W * C;
+        const float fy = (float)oy;
+        uint8_t v[16];
+        const int x0 = xq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ox = x0 + i;
+            const float fx = (float)ox;
+            const float proj = (c0 * fx + c1 * fy) + 1.0f;
+            const float ix = ((a0 * fx + a1 * fy) + a2) / proj;
+            const float iy = ((b0 * fx + b1 * fy) + b2) / proj;
+            const float rx = roundf(ix), ry = roundf(iy);  // half away from zero
+            const bool ok = (proj != 0.0f) && (rx >= 0.0f) && (rx < (float)W) && (ry >= 0.0f) && (ry < (float)H);
+            const int64_t src = ok ? ((int64_t)(int)ry * W + (int)rx) * C : 0;
+            for (int c = 0; c < C; ++c) v[i * C + c] = ok ? img[src + c] : (uint8_t)fill;
+        }
+        if (C == 3 && (W & 3) == 0) {
+            uint8_t b[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = v[i];
+            *reinterpret_cast<px4_t*>(orow + (int64_t)x0 * 3) = pack12(b);
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (x0 + i < W)
+                    for (int c = 0; c < C; ++c) orow[(int64_t)(x0 + i) * C + c] = v[i * C + c];
+        }
+    }
+}
+
+// ---- cutout (tfa.image.random_cutout with explicit centres), :495-499 -------------
+__global__ void __launch_bounds__(256) cutout_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
+                                                     int W, int C, const int32_t* __restrict__ centers, int half,
+                                                     int value) {
+    const int wq = (W + 3) >> 2;
+    const int64_t total = (int64_t)B * H * wq;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const int xq = (int)(q % wq);
+        const int64_t r = q / wq;
+        const int y = (int)(r % H);
+        const int n = (int)(r / H);
+        const int cy = centers[2 * n], cx = centers[2 * n + 1];
+        const int y0 = max(0, cy - half), y1 = min(H, cy + half);
+        const int xa = max(0, cx - half), xb = min(W, cx + half);
+        const bool rowin = (y >= y0) && (y < y1);
+        const int64_t rowoff = ((int64_t)n * H + y) * (int64_t)W * C;
+        const int x0 = xq * 4;
+        if (C == 3 && (W & 3) == 0) {
+            px4_t p = *reinterpret_cast<const px4_t*>(in + rowoff + (int64_t)x0 * 3);
+            uint8_t b[12];
+            unpack12(p, b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool inside = rowin && (x0 + i >= xa) && (x0 + i < xb);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)value : b[3 * i + c];
+            }
+            *reinterpret_cast<px4_t*>(out + rowoff + (int64_t)x0 * 3) = pack12(b);
+        } else {
+            for (int i = 0; i < 4; ++i) {
+                const int x = x0 + i;
+                if (x >= W) break;
+                const bool inside = rowin && (x >= xa) && (x < xb);
+                for (int c = 0; c < C; ++c) {
+                    const int64_t o = rowoff + (int64_t)x * C + c;
+                    out[o] = inside ? (uint8_t)value : in[o];
+                }
+            }
+        }
+    }
+}
+
+// ---- per-image, per-channel statistics (AutoContrast min/max, Equalize histogram) ----
+__global__ void stats_init_kernel(int32_t* ws, int n, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ws[i] = (mode == 0) ? ((i & 1) ? 0 : 255) : 0;  // mode 0: [min,max] pairs; mode 1: histogram
+}
+
+// grid = (slices, B).  C == 3 fast path reads 12-byte groups; generic path reads bytes.
+__global__ void __launch_bounds__(256) minmax_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ ws, int HW, int C) {
+    const int n = blockIdx.y;
+    const uint8_t* img = in + (int64_t)n * HW * C;
+    int lo[4] = {255, 255, 255, 255}, hi[4] = {0, 0, 0, 0};
+    const int64_t nbytes = (int64_t)HW * C;
+    if (C == 3) {
+        const int64_t ng = nbytes / 12;
+        const px4_t* p4 = reinterpret_cast<const px4_t*>(img);
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (int64_t)gridDim.x * blockDim.x) {
+            uint8_t b[12];
+            unpack12(p4[g], b);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                lo[i % 3] = min(lo[i % 3], (int)b[i]);
+                hi[i % 3] = max(hi[i % 3], (int)b[i]);
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int64_t i = ng * 12; i < nbytes; ++i) {
+                lo[i % 3] = min(lo[i % 3], (int)img[i]);
+                hi[i % 3] = max(hi[i % 3], (int)img[i]);
+            }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x) {
+            const int c = (int)(i % C);
+            lo[c] = min(lo[c], (int)img[i]);
+            hi[c] = max(hi[c], (int)img[i]);
+        }
+    }
+    for (int c = 0; c < C; ++c) {
+        int l = lo[c], h = hi[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            l = min(l, __shfl_xor(l, o, 64));
+            h = max(h, __shfl_xor(h, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&ws[(n * C + c) * 2 + 0], l);
+            atomicMax(&ws[(n * C + c) * 2 + 1], h);
+        }
+    }
+}
+
+// AutoContrast apply, :72-86
+__global__ void __launch_bounds__(256) autocontrast_apply_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                                 const int32_t* __restrict__ ws, int HW, int C) {
+    const int n = blockIdx.y;
+    float scale[4], offset[4];
+    for (int c = 0; c < C; ++c) {
+        const float lo = (float)ws[(n * C + c) * 2], hi = (float)ws[(n * C + c) * 2 + 1];
+        const float rng = hi - lo;
+        float s = (rng != 0.0f) ? 255.0f / rng : 0.0f;  // divide_no_nan
+        float o = (-lo) * s;
+        const float mask = hi > lo ? 1.0f : 0.0f;
+        s = s * mask + (1.0f - mask);
+        o = o * mask;
+        scale[c] = s;
+        offset[c] = o;
+    }
+    const int64_t base = (int64_t)n * HW * C;
+    const int64_t nbytes = (int64_t)HW * C;
+    if (C == 3) {
+        const int64_t ng = nbytes / 12;
+        const px4_t* p4 = reinterpret_cast<const px4_t*>(in + base);
+        px4_t* o4 = reinterpret_cast<px4_t*>(out + base);
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (int64_t)gridDim.x * blockDim.x) {
+            uint8_t b[12];
+            unpack12(p4[g], b);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                float v = (float)b[i] * scale[i % 3];
+                v = v + offset[i % 3];
+                v = fminf(fmaxf(v, 0.0f), 255.0f);
+                b[i] = trunc_u8(v);
+            }
+            o4[g] = pack12(b);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int64_t i = ng * 12; i < nbytes; ++i) {
+                float v = (float)in[base + i] * scale[i % 3];
+                v = v + offset[i % 3];
+                v = fminf(fmaxf(v, 0.0f), 255.0f);
+                out[base + i] = trunc_u8(v);
+            }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x) {
+            const int c = (int)(i % C);
+            float v = (float)in[base + i] * scale[c];
+            v = v + offset[c];
+            v = fminf(fmaxf(v, 0.0f), 255.0f);
+            out[base + i] = trunc_u8(v);
+        }
+    }
+}
+
+// Equalize pass 1: per-block LDS histogram (C <= 4), merged with global atomics.
+__global__ void __launch_bounds__(256) hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ ws, int HW, int C) {
+    __shared__ int32_t h[4 * 256];
+    for (int i = threadIdx.x; i < C * 256; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int n = blockIdx.y;
+    const uint8_t* img = in + (int64_t)n * HW * C;
+    const int64_t nbytes = (int64_t)HW * C;
+    if (C == 3) {
+        const int64_t ng = nbytes / 12;
+        const px4_t* p4 = reinterpret_cast<const px4_t*>(img);
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (int64_t)gridDim.x * blockDim.x) {
+            uint8_t b[12];
+            unpack12(p4[g], b);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) atomicAdd(&h[(i % 3) * 256 + b[i]], 1);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int64_t i = ng * 12; i < nbytes; ++i) atomicAdd(&h[(i % 3) * 256 + img[i]], 1);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x)
+            atomicAdd(&h[(int)(i % C) * 256 + img[i]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 256; i += blockDim.x)
+        if (h[i]) atomicAdd(&ws[(int64_t)n * C * 256 + i], h[i]);
+}
+
+// Equalize pass 2: histogram -> LUT in place (tfa.image.equalize _scale_channel).
+// grid = B*C blocks of 256 threads; bin i owned by thread i.
+__global__ void __launch_bounds__(256) equalize_lut_kernel(int32_t* __restrict__ ws) {
+    __shared__ int32_t s[256];
+    __shared__ int32_t last_nz;
+    int32_t* h = ws + (int64_t)blockIdx.x * 256;
+    const int t = threadIdx.x;
+    const int32_t mine = h[t];
+    s[t] = mine;
+    if (t == 0) last_nz = 0;
+    __syncthreads();
+    if (mine != 0) atomicMax(&last_nz, t);
+    // inclusive scan (Hillis-Steele) over 256 bins
+    for (int o = 1; o < 256; o <<= 1) {
+        const int32_t v = (t >= o) ? s[t - o] : 0;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    const int32_t total = s[255];
+    const int32_t excl = s[t] - mine;
+    const int32_t step = (total - h[last_nz]) / 255;
+    __syncthreads();
+    int32_t lut = t;
+    if (step != 0) {
+        lut = (excl + step / 2) / step;
+        lut = lut < 0 ? 0 : (lut > 255 ? 255 : lut);
+    }
+    h[t] = lut;
+}
+
+// Equalize pass 3: out = lut[n][c][in]
+__global__ void __launch_bounds__(256) lut_apply_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        const int32_t* __restrict__ ws, int HW, int C) {
+    __shared__ uint8_t lut[4 * 256];
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < C * 256; i += blockDim.x) lut[i] = (uint8_t)ws[(int64_t)n * C * 256 + i];
+    __syncthreads();
+    const int64_t base = (int64_t)n * HW * C;
+    const int64_t nbytes = (int64_t)HW * C;
+    if (C == 3) {
+        const int64_t ng = nbytes / 12;
+        const px4_t* p4 = reinterpret_cast<const px4_t*>(in + base);
+        px4_t* o4 = reinterpret_cast<px4_t*>(out + base);
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (int64_t)gridDim.x * blockDim.x) {
+            uint8_t b[12];
+            unpack12(p4[g], b);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
+            o4[g] = pack12(b);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int64_t i = ng * 12; i < nbytes; ++i) out[base + i] = lut[(i % 3) * 256 + in[base + i]];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x)
+            out[base + i] = lut[(int)(i % C) * 256 + in[base + i]];
+    }
+}
+
+// ---- Sharpness (tfa.image.sharpness), :303-304 ---------------------------------------
+// One thread = 4 output pixels of one row; rows of the 3x3 window come through L1/L2.
+template <int MODE>  // 0: factor==0 (degenerate only), 1: 0<f<1 (no clip), 2: clip
+__global__ void __launch_bounds__(256) sharpness_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
+                                                        int W, int C, float factor) {
+    const int wq = (W + 3) >> 2;
+    const int64_t total = (int64_t)B * H * wq;
+    const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(q % wq);
+        const int64_t r = q / wq;
+        const int y = (int)(r % H);
+        const int n = (int)(r / H);
+        const uint8_t* img = in + (int64_t)n * H * W * C;
+        const int64_t rowoff = ((int64_t)n * H + y) * (int64_t)W * C;
+        const bool yin = (y >= 1) && (y < H - 1);
+        for (int i = 0; i < 4; ++i) {
+            const int x = xq * 4 + i;
+            if (x >= W) break;
+            const bool interior = yin && (x >= 1) && (x < W - 1);
+            for (int c = 0; c < C; ++c) {
+                const uint8_t orig = img[((int64_t)y * W + x) * C + c];
+                uint8_t deg = orig;
+                if (interior) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int ky = -1; ky <= 1; ++ky)
+#pragma unroll
+                        for (int kx = -1; kx <= 1; ++kx) {
+                            const float v = (float)img[((int64_t)(y + ky) * W + (x + kx)) * C + c];
+                            acc = acc + v * ((ky == 0 && kx == 0) ? k5 : k1);
+                        }
+                    deg = trunc_u8(acc);
+                }
+                uint8_t res;
+                if (MODE == 0) res = deg;
+                else if (MODE == 1) res = blend1<false>(deg, orig, factor);
+                else res = blend1<true>(deg, orig, factor);
+                out[rowoff + (int64_t)x * C + c] = res;
+            }
+        }
+    }
+}
+
+// ---- ImageNetNormalization, :629-682 ---------------------------------------------------
+struct NormConst { float mean[3]; float stdv[3]; };
+
+template <int MODE, typename TIN>  // 0 caffe, 1 tf, 2 torch
+__device__ __forceinline__ float norm1(TIN xin, int c, const NormConst& nc) {
+    const float x = (float)xin;
+    if (MODE == 1) {
+        float v = x / 127.5f;
+        return v - 1.0f;
+    } else if (MODE == 2) {
+        float v = x / 255.0f;
+        v = v - nc.mean[c];
+        return v / nc.stdv[c];
+    } else {
+        return x - nc.mean[c];
+    }
+}
+
+template <int MODE, typename TIN>
+__global__ void __launch_bounds__(256) normalize_kernel(const TIN* __restrict__ in, float* __restrict__ out, int64_t n_pixels, NormConst nc) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pixels; p += (int64_t)gridDim.x * blockDim.x) {
+        const TIN* s = in + p * 3;
+        float* d = out + p * 3;
+        if (MODE == 0) {  // RGB -> BGR then subtract mean (:647-650)
+            const TIN r = s[0], g = s[1], b = s[2];
+            d[0] = norm1<0>(b, 0, nc);
+            d[1] = norm1<0>(g, 1, nc);
+            d[2] = norm1<0>(r, 2, nc);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = norm1<MODE>(s[c], c, nc);
+        }
+    }
+}
+
+// mode "tf" for any channel count (elementwise), 12 bytes -> 12 floats per thread
+__global__ void __launch_bounds__(256) normalize_tf_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n_groups,
+                                                              int64_t n_bytes) {
+    const px4_t* in4 = reinterpret_cast<const px4_t*>(in);
+    float4* out4 = reinterpret_cast<float4*>(out);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t b[12];
+        unpack12(in4[g], b);
+        float f[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            float v = (float)b[i] / 127.5f;
+            f[i] = v - 1.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out4[g * 3 + i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = n_groups * 12; i < n_bytes; ++i) {
+            float v = (float)in[i] / 127.5f;
+            out[i] = v - 1.0f;
+        }
+}
+
+// Normalise (mode tf/torch/caffe) + patchify: uint8 NHWC -> bf16 [B*gh*gw, p*p*3] rows, the
+// A operand of the patch-embedding GEMM (vision_transformer.py:235-248 Conv2D k=s=p 'valid' is
+// a pure gather for NHWC input).  One thread = 4 pixels of one image row (p % 4 == 0).
+template <int MODE>
+__global__ void __launch_bounds__(256) normalize_patchify_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int B, int H,
+                                                                 int W, int P, int gh, int gw, NormConst nc) {
+    const int wq = (gw * P) >> 2;
+    const int hh = gh * P;
+    const int64_t total = (int64_t)B * hh * wq;
+    const int K = P * P * 3;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(q % wq);
+        const int64_t r = q / wq;
+        const int y = (int)(r % hh);
+        const int n = (int)(r / hh);
+        const int x0 = xq * 4;
+        const uint8_t* s = in + (((int64_t)n * H + y) * W + x0) * 3;
+        uint8_t b[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b[i] = s[i];
+        float f[12];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (MODE == 0) {
+                f[3 * p + 0] = norm1<0>(b[3 * p + 2], 0, nc);
+                f[3 * p + 1] = norm1<0>(b[3 * p + 1], 1, nc);
+                f[3 * p + 2] = norm1<0>(b[3 * p + 0], 2, nc);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) f[3 * p + c] = norm1<MODE>(b[3 * p + c], c, nc);
+            }
+        }
+        const int64_t row = ((int64_t)n * gh + y / P) * gw + x0 / P;
+        const int col = ((y % P) * P + (x0 % P)) * 3;
+        uint32_t* d = reinterpret_cast<uint32_t*>(out + row * K + col);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    }
+}
+
+// float32 NHWC (already normalised, the reference model's own input) -> bf16 patch rows
+__global__ void __launch_bounds__(256) patchify_f32_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int B, int H, int W, int P,
+                                                           int gh, int gw) {
+    const int wq = (gw * P) >> 2;
+    const int hh = gh * P;
+    const int64_t total = (int64_t)B * hh * wq;
+    const int K = P * P * 3;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(q % wq);
+        const int64_t r = q / wq;
+        const int y = (int)(r % hh);
+        const int n = (int)(r / hh);
+        const int x0 = xq * 4;
+        const float* s = in + (((int64_t)n * H + y) * W + x0) * 3;
+        const int64_t row = ((int64_t)n * gh + y / P) * gw + x0 / P;
+        const int col = ((y % P) * P + (x0 % P)) * 3;
+        uint32_t* d = reinterpret_cast<uint32_t*>(out + row * K + col);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(s[2 * i], s[2 * i + 1]);
+    }
+}
+
+const NormConst kCaffe = {{103.939f, 116.779f, 123.68f}, {1.f, 1.f, 1.f}};
+const NormConst kTorch = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};
+
+}  // namespace
+
+extern "C" {
+
+int chb_aug_pointwise(const uint8_t* in, uint8_t* out, int64_t n_bytes, int op, float factor, int i0, int i1, void* stream) {
+    if (!in || !out || n_bytes < 0) return CHB_EINVAL;
+    if (n_bytes == 0) return CHB_OK;
+    if (((uintptr_t)in & 3) || ((uintptr_t)out & 3)) return CHB_EINVAL;
+    if (op == CHB_PW_COLOR && (n_bytes % 3) != 0) return CHB_EINVAL;
+    PwParams pp{op, factor, i0, i1};
+    const int64_t ng = n_bytes / 12;
+    const int grid = stream_grid(ng);
+    hipStream_t s = (hipStream_t)stream;
+#define CHB_PW_CASE(OP) \
+    case OP: hipLaunchKernelGGL(pointwise_kernel<OP>, dim3(grid), dim3(256), 0, s, in, out, ng, n_bytes, pp); break;
+    switch (op) {
+        CHB_PW_CASE(CHB_PW_INVERT)
+        CHB_PW_CASE(CHB_PW_POSTERIZE)
+        CHB_PW_CASE(CHB_PW_SOLARIZE)
+        CHB_PW_CASE(CHB_PW_SOLARIZE_ADD)
+        CHB_PW_CASE(CHB_PW_BRIGHTNESS)
+        CHB_PW_CASE(CHB_PW_CONTRAST)
+        CHB_PW_CASE(CHB_PW_COLOR)
+        default: return CHB_EINVAL;
+    }
+#undef CHB_PW_CASE
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, const float* transform_host8,
+                   const float* transforms_dev, int per_image, int fill, void* stream) {
+    if (!in || !out || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
+    if (!transform_host8 && !transforms_dev) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    float t[8] = {1, 0, 0, 0, 1, 0, 0, 0};
+    if (transform_host8) for (int i = 0; i < 8; ++i) t[i] = transform_host8[i];
+    const int64_t total = (int64_t)B * H * ((W + 3) / 4);
+    hipLaunchKernelGGL(affine_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
+                       transform_host8 ? nullptr : transforms_dev, per_image, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
+                       fill & 0xff);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_aug_cutout(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, const int32_t* centers_dev, int mask_size,
+                   int value, void* stream) {
+    if (!in || !out || !centers_dev || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
+    if (mask_size < 0 || (mask_size & 1)) return CHB_EINVAL;  // tfa: mask_size must be even
+    if (B == 0) return CHB_OK;
+    const int64_t total = (int64_t)B * H * ((W + 3) / 4);
+    hipLaunchKernelGGL(cutout_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
+                       centers_dev, mask_size / 2, value & 0xff);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+static int slices_for(int64_t bytes_per_image, int B) {
+    // enough blocks to fill 256 CUs x 8 even for small batches
+    int64_t per = (bytes_per_image / 12 + 255) / 256;
+    int64_t want = (2048 + B - 1) / (B > 0 ? B : 1);
+    if (want < 1) want = 1;
+    if (per < 1) per = 1;
+    return (int)(want < per ? want : per);
+}
+
+int chb_aug_autocontrast(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, int32_t* workspace, void* stream) {
+    if (!in || !out || !workspace || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nws = B * C * 2;
+    hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, workspace, nws, 0);
+    const int sl = slices_for((int64_t)H * W * C, B);
+    hipLaunchKernelGGL(minmax_kernel, dim3(sl, B), dim3(256), 0, s, in, workspace, H * W, C);
+    hipLaunchKernelGGL(autocontrast_apply_kernel, dim3(sl, B), dim3(256), 0, s, in, out, workspace, H * W, C);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_aug_equalize(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, int32_t* workspace, void* stream) {
+    if (!in || !out || !workspace || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nws = B * C * 256;
+    hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, workspace, nws, 1);
+    const int sl = slices_for((int64_t)H * W * C, B);
+    hipLaunchKernelGGL(hist_kernel, dim3(sl, B), dim3(256), 0, s, in, workspace, H * W, C);
+    hipLaunchKernelGGL(equalize_lut_kernel, dim3(B * C), dim3(256), 0, s, workspace);
+    hipLaunchKernelGGL(lut_apply_kernel, dim3(sl, B), dim3(256), 0, s, in, out, workspace, H * W, C);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_aug_sharpness(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, float factor, void* stream) {
+    if (!in || !out || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    const int64_t total = (int64_t)B * H * ((W + 3) / 4);
+    const int grid = stream_grid(total);
+    hipStream_t s = (hipStream_t)stream;
+    if (factor == 0.0f) hipLaunchKernelGGL(sharpness_kernel<0>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C, factor);
+    else if (factor > 0.0f && factor < 1.0f) hipLaunchKernelGGL(sharpness_kernel<1>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C, factor);
+    else hipLaunchKernelGGL(sharpness_kernel<2>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C, factor);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_normalize_u8(const uint8_t* in, float* out, int64_t n_pixels, int channels, int mode, void* stream) {
+    if (!in || !out || n_pixels < 0 || channels <= 0) return CHB_EINVAL;
+    if (n_pixels == 0) return CHB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == CHB_NORM_TF) {
+        const int64_t nb = n_pixels * channels;
+        if (((uintptr_t)in & 3) || ((uintptr_t)out & 15)) return CHB_EINVAL;
+        hipLaunchKernelGGL(normalize_tf_u8_kernel, dim3(stream_grid(nb / 12)), dim3(256), 0, s, in, out, nb / 12, nb);
+    } else if (channels != 3) {
+        return CHB_EINVAL;  // caffe/torch carry 3-channel constants (:649,:656)
+    } else if (mode == CHB_NORM_CAFFE) {
+        hipLaunchKernelGGL((normalize_kernel<0, uint8_t>), dim3(stream_grid(n_pixels)), dim3(256), 0, s, in, out, n_pixels, kCaffe);
+    } else if (mode == CHB_NORM_TORCH) {
+        hipLaunchKernelGGL((normalize_kernel<2, uint8_t>), dim3(stream_grid(n_pixels)), dim3(256), 0, s, in, out, n_pixels, kTorch);
+    } else {
+        return CHB_EINVAL;
+    }
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_normalize_f32(const float* in, float* out, int64_t n_pixels, int channels, int mode, void* stream) {
+    if (!in || !out || n_pixels < 0 || channels != 3) return CHB_EINVAL;
+    if (n_pixels == 0) return CHB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = stream_grid(n_pixels);
+    if (mode == CHB_NORM_TF) hipLaunchKernelGGL((normalize_kernel<1, float>), dim3(grid), dim3(256), 0, s, in, out, n_pixels, kCaffe);
+    else if (mode == CHB_NORM_CAFFE) hipLaunchKernelGGL((normalize_kernel<0, float>), dim3(grid), dim3(256), 0, s, in, out, n_pixels, kCaffe);
+    else if (mode == CHB_NORM_TORCH) hipLaunchKernelGGL((normalize_kernel<2, float>), dim3(grid), dim3(256), 0, s, in, out, n_pixels, kTorch);
+    else return CHB_EINVAL;
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_normalize_patchify_bf16(const uint8_t* in, void* out, int B, int H, int W, int patch, int mode, void* stream) {
+    if (!in || !out || B < 0 || H <= 0 || W <= 0 || patch <= 0 || (patch & 3)) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    const int gh = H / patch, gw = W / patch;
+    if (gh == 0 || gw == 0) return CHB_EINVAL;
+    const int64_t total = (int64_t)B * gh * patch * ((gw * patch) / 4);
+    const int grid = stream_grid(total);
+    hipStream_t s = (hipStream_t)stream;
+    bf16_t* o = (bf16_t*)out;
+    if (mode == CHB_NORM_TF) hipLaunchKernelGGL(normalize_patchify_kernel<1>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
+    else if (mode == CHB_NORM_CAFFE) hipLaunchKernelGGL(normalize_patchify_kernel<0>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
+    else if (mode == CHB_NORM_TORCH) hipLaunchKernelGGL(normalize_patchify_kernel<2>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kTorch);
+    else return CHB_EINVAL;
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_patchify_f32_bf16(const float* in, void* out, int B, int H, int W, int patch, void* stream) {
+    if (!in || !out || B < 0 || H <= 0 || W <= 0 || patch <= 0 || (patch & 3)) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    const int gh = H / patch, gw = W / patch;
+    if (gh == 0 || gw == 0) return CHB_EINVAL;
+    const int64_t total = (int64_t)B * gh * patch * ((gw * patch) / 4);
+    hipLaunchKernelGGL(patchify_f32_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, B, H, W, patch,
+                       gh, gw);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+}  // extern "C"

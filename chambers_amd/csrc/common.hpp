@@ -1,0 +1,96 @@
+// Shared device helpers for the chambers MI355X (gfx950) kernels.
+// Wavefront = 64 lanes everywhere in this tree; no 32-wide idioms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CHB_OK 0
+#define CHB_EINVAL (-1)
+#define CHB_ELAUNCH (-2)
+#define CHB_EUNSUPPORTED (-3)
+
+#define CHB_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return CHB_ELAUNCH;           \
+    } while (0)
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+typedef __attribute__((ext_vector_type(16))) float float16_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// round-to-nearest-even; a plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- counter-hash RNG for dropout (definition: oracle/rng_ref.py) -------------
+__device__ __forceinline__ uint32_t chb_hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+// 16-bit uniform of flat element index e under site key `key`
+__device__ __forceinline__ uint32_t chb_u16(uint64_t e, uint32_t key) {
+    uint32_t r = chb_hash32(((uint32_t)(e >> 1)) ^ key);
+    return (r >> (16u * (uint32_t)(e & 1))) & 0xffffu;
+}
+
+__device__ __forceinline__ bool chb_keep(uint64_t e, uint32_t key, uint32_t thr) {
+    return chb_u16(e, key) >= thr;
+}
+
+// both halves of one hash: elements 2c and 2c+1
+__device__ __forceinline__ void chb_keep2(uint32_t c, uint32_t key, uint32_t thr, bool& k0, bool& k1) {
+    uint32_t r = chb_hash32(c ^ key);
+    k0 = (r & 0xffffu) >= thr;
+    k1 = (r >> 16) >= thr;
+}
+
+__host__ __device__ __forceinline__ uint32_t chb_drop_threshold(float rate) {
+    return (uint32_t)(rate * 65536.0f + 0.5f);
+}
+
+// ---- wave / block reductions ----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU and its derivative (activations.py:46-56)
+__device__ __forceinline__ float gelu_f(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+static inline int chb_div_up(long a, long b) { return (int)((a + b - 1) / b); }

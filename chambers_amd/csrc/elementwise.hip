@@ -1,0 +1,280 @@
+// HBM-bound glue around the ViT block on gfx950: dropout masks, embedding-stage forward and
+// backward pieces, bias-gradient column sums, sparse softmax cross-entropy, the per-step
+// fp32 -> bf16 (+transposed) weight refresh and the fused AdamW update.
+//
+// Reference call sites: keras Dropout (vision_transformer.py:261, layers/transformer.py:38,48),
+// ConcatEmbedding / LearnedEmbedding1D (layers/embedding.py:179-180,251-261),
+// AdamW (optimizers.py:147-155,372-464).
+#include "common.hpp"
+#include "../../include/chambers_hip.h"
+
+namespace {
+
+inline int grid_for(int64_t n, int cap = 8192) {
+    int64_t b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+__global__ void dropout_mask_kernel(uint8_t* out, int64_t n, uint32_t thr, uint32_t key) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = chb_keep((uint64_t)e, key, thr) ? 1 : 0;
+}
+
+__global__ void cls_row_kernel(float* x, const float* cls, const float* pos, int B, int N, int D, float scale, uint32_t thr,
+                               uint32_t key) {
+    const int64_t total = (int64_t)B * D;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(t / D), d = (int)(t - (int64_t)b * D);
+        const int64_t e = (int64_t)b * N * D + d;
+        float v = cls[d] + pos[d];
+        if (thr) v = chb_keep((uint64_t)e, key, thr) ? v * scale : 0.f;
+        x[e] = v;
+    }
+}
+
+// thread = (token t, 4 columns); loops over the batch: dpos[t] = sum_b dz[b,t], dcls = dpos[0],
+// dpatch[b, t-1] = bf16(dz[b,t]) for t >= 1, with dz = dx * keep * scale.
+__global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dpatch, float* __restrict__ dpos,
+                                                        float* __restrict__ dcls, int B, int N, int D, float scale, uint32_t thr,
+                                                        uint32_t key) {
+    const int dq = D >> 2;
+    const int64_t total = (int64_t)N * dq;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx / dq), d = (int)(idx - (int64_t)t * dq) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < B; ++b) {
+            const int64_t e = ((int64_t)b * N + t) * D + d;
+            float4 v = *reinterpret_cast<const float4*>(dx + e);
+            if (thr) {
+                bool k0, k1, k2, k3;
+                chb_keep2((uint32_t)(e >> 1), key, thr, k0, k1);
+                chb_keep2((uint32_t)(e >> 1) + 1u, key, thr, k2, k3);
+                v.x = k0 ? v.x * scale : 0.f; v.y = k1 ? v.y * scale : 0.f;
+                v.z = k2 ? v.z * scale : 0.f; v.w = k3 ? v.w * scale : 0.f;
+            }
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            if (t >= 1) {
+                uint2 o;
+                o.x = pack_bf16x2(v.x, v.y);
+                o.y = pack_bf16x2(v.z, v.w);
+                *reinterpret_cast<uint2*>(dpatch + ((int64_t)b * (N - 1) + (t - 1)) * D + d) = o;
+            }
+        }
+        *reinterpret_cast<float4*>(dpos + (int64_t)t * D + d) = acc;
+        if (t == 0) *reinterpret_cast<float4*>(dcls + d) = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) dropout_bwd_kernel(const float* __restrict__ dy, int64_t ld, bf16_t* __restrict__ dz, int M, int N,
+                                                          float scale, uint32_t thr, uint32_t key) {
+    const int nq = N >> 2;
+    const int64_t total = (int64_t)M * nq;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / nq;
+        const int c = (int)(idx - r * nq) * 4;
+        float4 v = *reinterpret_cast<const float4*>(dy + r * ld + c);
+        if (thr) {
+            const uint64_t e = (uint64_t)r * (uint64_t)N + (uint64_t)c;
+            bool k0, k1, k2, k3;
+            chb_keep2((uint32_t)(e >> 1), key, thr, k0, k1);
+            chb_keep2((uint32_t)(e >> 1) + 1u, key, thr, k2, k3);
+            v.x = k0 ? v.x * scale : 0.f; v.y = k1 ? v.y * scale : 0.f;
+            v.z = k2 ? v.z * scale : 0.f; v.w = k3 ? v.w * scale : 0.f;
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v.x, v.y);
+        o.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(dz + r * (int64_t)N + c) = o;
+    }
+}
+
+// grid = (col blocks of 256 columns, row slabs of 512 rows); lane owns 4 columns.
+__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ x, int64_t ld, float* __restrict__ out, int M, int N) {
+    __shared__ float red[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int r0 = blockIdx.y * 512;
+    int r1 = r0 + 512;
+    r1 = r1 < M ? r1 : M;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < N) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const uint2 v = *reinterpret_cast<const uint2*>(x + (int64_t)r * ld + c);
+            acc.x += bf16_to_f32((bf16_t)(v.x & 0xffff)); acc.y += bf16_to_f32((bf16_t)(v.x >> 16));
+            acc.z += bf16_to_f32((bf16_t)(v.y & 0xffff)); acc.w += bf16_to_f32((bf16_t)(v.y >> 16));
+        }
+    }
+    red[wave][lane * 4 + 0] = acc.x; red[wave][lane * 4 + 1] = acc.y;
+    red[wave][lane * 4 + 2] = acc.z; red[wave][lane * 4 + 3] = acc.w;
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < N) atomicAdd(out + cc, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+// one wave per sample
+__global__ void __launch_bounds__(256) softmax_ce_kernel(const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
+                                                         float* __restrict__ loss, bf16_t* __restrict__ dl, int64_t ld_d, int B,
+                                                         int classes, float grad_scale) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+        const float* z = logits + (int64_t)b * ld;
+        float mx = -INFINITY;
+        for (int c = lane; c < classes; c += 64) mx = fmaxf(mx, z[c]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int c = lane; c < classes; c += 64) s += expf(z[c] - mx);
+        s = wave_sum(s);
+        const int lab = labels[b];
+        const float lse = mx + logf(s);
+        if (lane == 0) loss[b] = lse - z[lab];
+        if (dl) {
+            bf16_t* d = dl + (int64_t)b * ld_d;
+            const float inv = 1.0f / s;
+            for (int c = lane; c < (int)ld_d; c += 64) {
+                float g = 0.f;
+                if (c < classes) g = (expf(z[c] - mx) * inv - (c == lab ? 1.0f : 0.0f)) * grad_scale;
+                d[c] = f32_to_bf16(g);
+            }
+        }
+    }
+}
+
+// grid = (tiles, matrices); 64x64 tile through LDS; desc = {src_off, dst_off, R, C}
+__global__ void __launch_bounds__(256) cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, bf16_t* __restrict__ dst_t,
+                                                             const int64_t* __restrict__ desc) {
+    __shared__ bf16_t tile[64][66];
+    const int64_t* d = desc + (int64_t)blockIdx.y * 4;
+    const int64_t so = d[0], dof = d[1];
+    const int R = (int)d[2], C = (int)d[3];
+    const int tc = (C + 63) / 64, tr = (R + 63) / 64;
+    if ((int)blockIdx.x >= tc * tr) return;
+    const int r0 = ((int)blockIdx.x / tc) * 64, c0 = ((int)blockIdx.x % tc) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int r = r0 + rr, c = c0 + tx;
+        bf16_t v = 0;
+        if (r < R && c < C) {
+            v = f32_to_bf16(src[so + (int64_t)r * C + c]);
+            if (dst) dst[dof + (int64_t)r * C + c] = v;
+        }
+        tile[rr][tx] = v;
+    }
+    if (!dst_t) return;
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, r = r0 + tx;
+        if (r < R && c < C) dst_t[dof + (int64_t)c * R + r] = tile[tx][cc];
+    }
+}
+
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    const uint8_t* __restrict__ flags, int64_t n4, float lr_t, float b1c, float b2c, float eps,
+                                                    float wd, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        const bool decay = flags ? (flags[i >> 8] != 0) : true;  // 1024-element chunks = 256 float4
+        float* pp = &pv.x; const float* gg = &gv.x; float* mm = &mv.x; float* vq = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gscale;
+            float w = pp[k];
+            if (decay) w = w - wd * w;                       // optimizers.py:147-155: decay first, wd not scaled by lr
+            mm[k] = mm[k] + (gk - mm[k]) * b1c;              // keras Adam: m += (g - m)(1 - b1)
+            vq[k] = vq[k] + (gk * gk - vq[k]) * b2c;
+            pp[k] = w - lr_t * mm[k] / (sqrtf(vq[k]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int chb_version(void) { return 1; }
+const char* chb_build_arch(void) { return "gfx950"; }
+
+int chb_dropout_mask(uint8_t* out, int64_t n, float rate, uint32_t key, void* stream) {
+    if (!out || n < 0 || rate < 0.f || rate >= 1.f) return CHB_EINVAL;
+    if (n == 0) return CHB_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       rate > 0.f ? chb_drop_threshold(rate) : 0u, key);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_cls_row(float* x, const float* cls, const float* pos, int B, int N, int D, float drop_rate, uint32_t drop_key, void* stream) {
+    if (!x || !cls || !pos || B < 0 || N <= 0 || D <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    hipLaunchKernelGGL(cls_row_kernel, dim3(grid_for((int64_t)B * D)), dim3(256), 0, (hipStream_t)stream, x, cls, pos, B, N, D,
+                       1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_embed_bwd(const float* dx, void* dpatch, float* dpos, float* dcls, int B, int N, int D, float drop_rate, uint32_t drop_key,
+                  void* stream) {
+    if (!dx || !dpatch || !dpos || !dcls || B < 0 || N <= 1 || D <= 0 || (D & 3) || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((int64_t)N * (D / 4))), dim3(256), 0, (hipStream_t)stream, dx, (bf16_t*)dpatch,
+                       dpos, dcls, B, N, D, 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_dropout_bwd_bf16(const float* dy, int64_t ld, void* dz, int M, int N, float drop_rate, uint32_t drop_key, void* stream) {
+    if (!dy || !dz || M < 0 || N <= 0 || (N & 3) || (ld & 3) || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
+    if (M == 0) return CHB_OK;
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((int64_t)M * (N / 4))), dim3(256), 0, (hipStream_t)stream, dy, ld, (bf16_t*)dz, M,
+                       N, 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_colsum_bf16(const void* x, int64_t ld, float* out, int M, int N, void* stream) {
+    if (!x || !out || M < 0 || N <= 0 || (N & 3) || (ld & 3)) return CHB_EINVAL;
+    if (M == 0) return CHB_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3(chb_div_up(N, 256), chb_div_up(M, 512)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
+                       out, M, N);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_softmax_ce(const float* logits, int64_t ld, const int32_t* labels, float* loss_per_sample, void* dlogits, int64_t ld_d, int B,
+                   int classes, float grad_scale, void* stream) {
+    if (!logits || !labels || !loss_per_sample || B < 0 || classes <= 0 || ld < classes) return CHB_EINVAL;
+    if (dlogits && ld_d < classes) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    int blocks = chb_div_up(B, 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss_per_sample,
+                       (bf16_t*)dlogits, ld_d, B, classes, grad_scale);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_cast_transpose(const float* src, void* dst, void* dst_t, const int64_t* desc, int n_desc, int max_tiles, void* stream) {
+    if (!src || !desc || n_desc < 0 || max_tiles <= 0 || (!dst && !dst_t)) return CHB_EINVAL;
+    if (n_desc == 0) return CHB_OK;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(max_tiles, n_desc), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+                       (bf16_t*)dst_t, desc);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay_flags, int64_t n, float lr_t, float beta1, float beta2,
+              float eps, float weight_decay, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n < 0 || (n & 3)) return CHB_EINVAL;
+    if (n == 0) return CHB_OK;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, decay_flags, n / 4, lr_t,
+                       1.0f - beta1, 1.0f - beta2, eps, weight_decay, grad_scale);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// LayerNormalization forward/backward for the ViT residual stream (gfx950).
+// HBM-bound: one wave owns one token row (D <= 1024 fp32 values = <= 4 float4 per lane),
+// statistics by wave shuffles, no LDS in the forward.  The residual stream is fp32, the
+// normalised output that feeds the MFMA GEMMs is bf16.
+//
+// Replaces tf.keras.layers.LayerNormalization(epsilon=1e-6) constructed at
+// chambers/layers/transformer.py:39,49,283 (moments + batch_normalization path).
+#include "common.hpp"
+#include "../../include/chambers_hip.h"
+
+namespace {
+
+template <int NCH>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, int64_t x_stride, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D,
+                                                     float eps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunk = D >> 2;
+    const float inv_d = 1.0f / (float)D;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * x_stride);
+        float4 v[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = (c < nchunk) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nchunk) {
+                const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float var = wave_sum(q) * inv_d;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+        uint2* yr = reinterpret_cast<uint2*>(y + (int64_t)row * D);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nchunk) {
+                const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+                const float4 b = reinterpret_cast<const float4*>(beta)[c];
+                uint2 o;
+                o.x = pack_bf16x2((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y);
+                o.y = pack_bf16x2((v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+                yr[c] = o;
+            }
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += dy*xhat; dbeta += dy.
+template <int NCH>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, int64_t x_stride,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx, int64_t dx_stride,
+                                                     int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                     int D) {
+    __shared__ float red[2][4][NCH * 256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunk = D >> 2;
+    const float inv_d = 1.0f / (float)D;
+    float4 gam[NCH], dg[NCH], db[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+        gam[j] = (c < nchunk) ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * x_stride);
+        const uint2* dyr = reinterpret_cast<const uint2*>(dy + (int64_t)row * D);
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float4 xh[NCH], gy[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nchunk) {
+                const float4 xv = xr[c];
+                const uint2 dv = dyr[c];
+                const float d0 = bf16_to_f32((bf16_t)(dv.x & 0xffff)), d1 = bf16_to_f32((bf16_t)(dv.x >> 16));
+                const float d2 = bf16_to_f32((bf16_t)(dv.y & 0xffff)), d3 = bf16_to_f32((bf16_t)(dv.y >> 16));
+                xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                gy[j] = make_float4(d0 * gam[j].x, d1 * gam[j].y, d2 * gam[j].z, d3 * gam[j].w);
+                s1 += (gy[j].x + gy[j].y) + (gy[j].z + gy[j].w);
+                s2 += (gy[j].x * xh[j].x + gy[j].y * xh[j].y) + (gy[j].z * xh[j].z + gy[j].w * xh[j].w);
+                dg[j].x += d0 * xh[j].x; dg[j].y += d1 * xh[j].y; dg[j].z += d2 * xh[j].z; dg[j].w += d3 * xh[j].w;
+                db[j].x += d0; db[j].y += d1; db[j].z += d2; db[j].w += d3;
+            } else {
+                xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                gy[j] = xh[j];
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
+        float4* dxr = reinterpret_cast<float4*>(dx + (int64_t)row * dx_stride);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nchunk) {
+                float4 o = make_float4(rstd * (gy[j].x - c1 - xh[j].x * c2), rstd * (gy[j].y - c1 - xh[j].y * c2),
+                                       rstd * (gy[j].z - c1 - xh[j].z * c2), rstd * (gy[j].w - c1 - xh[j].w * c2));
+                if (accumulate) {
+                    const float4 p = dxr[c];
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
+                dxr[c] = o;
+            }
+        }
+    }
+    // block-level reduce of dgamma/dbeta partials over the 4 waves, then one atomic per column
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int base = (lane + 64 * j) * 4;
+        red[0][wave][base + 0] = dg[j].x; red[0][wave][base + 1] = dg[j].y;
+        red[0][wave][base + 2] = dg[j].z; red[0][wave][base + 3] = dg[j].w;
+        red[1][wave][base + 0] = db[j].x; red[1][wave][base + 1] = db[j].y;
+        red[1][wave][base + 2] = db[j].z; red[1][wave][base + 3] = db[j].w;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float g = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+        atomicAdd(dgamma + c, g);
+        atomicAdd(dbeta + c, b);
+    }
+}
+
+inline int ln_grid(int M) {
+    int blocks = (M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    return blocks < 1 ? 1 : blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int chb_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int M, int D, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || M < 0 || D <= 0) return CHB_EINVAL;
+    if ((D & 3) || D > 1024 || (x_stride & 3)) return CHB_EUNSUPPORTED;
+    if (M == 0) return CHB_OK;
+    const int nch = (D / 4 + 63) / 64;
+    const dim3 grid(ln_grid(M)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    bf16_t* yo = (bf16_t*)y;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps); break;
+        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps); break;
+        case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps); break;
+        default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps); break;
+    }
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_layernorm_bwd(const void* dy, const float* x, int64_t x_stride, const float* mean, const float* rstd, const float* gamma,
+                      float* dx, int64_t dx_stride, int accumulate, float* dgamma, float* dbeta, int M, int D, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || M < 0 || D <= 0) return CHB_EINVAL;
+    if ((D & 3) || D > 1024 || (x_stride & 3) || (dx_stride & 3)) return CHB_EUNSUPPORTED;
+    if (M == 0) return CHB_OK;
+    const int nch = (D / 4 + 63) / 64;
+    int blocks = (M + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    const dim3 grid(blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bf16_t* d = (const bf16_t*)dy;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D); break;
+        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D); break;
+    }
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,512 @@
+"""Whole-model ViT executor for MI355X: forward, backward, AdamW and data-parallel gradient
+exchange over preallocated HBM buffers, every arithmetic step a hand-written HIP kernel behind
+the C ABI (chambers_amd/kernels.py).  torch only allocates, zero-fills and provides streams /
+torch.distributed (RCCL).
+
+What it replaces in the reference: the Keras graph built by VisionTransformer
+(models/backbones/vision_transformer.py:235-283) executed by `Model.fit` with
+chambers.optimizers.AdamW (optimizers.py:372-464) — i.e. SURVEY §3.2-3.4.
+
+Numerics ("mixed_bfloat16"-like, utils/generic.py:32-40): fp32 master weights, bf16 GEMM/attention
+operands, fp32 accumulation; the residual stream and all gradients of it are kept in fp32 (one
+step more precise than Keras' bf16 activations).  Dropout masks come from the counter hash
+(chambers_amd/rng.py), regenerated in backward.
+
+Parameter memory: ONE flat fp32 buffer (+ same-shaped grad / Adam m / Adam v), laid out in the
+order gradients become final during backward (head, final norm, block L-1 ... block 0,
+embeddings) so that data-parallel buckets are contiguous slices that can be all-reduced while
+earlier blocks are still in backward.  Two bf16 images of the matrices are refreshed after every
+optimizer step: [K][N] (B operand of dgrad) and its transpose [N][K] (B operand of forward).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import rng
+
+ALIGN = 1024  # parameter tensors start at multiples of 1024 elements (16-byte vectors, AdamW decay chunks)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class ViTConfig:
+    def __init__(self, patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate=0.1, image_size=(224, 224),
+                 classes=1000, include_top=True, feature_dim=None, pooling="cls", norm_epsilon=1e-6, norm_mode="tf"):
+        self.patch_size, self.patch_dim, self.n_encoder_layers = int(patch_size), int(patch_dim), int(n_encoder_layers)
+        self.n_heads, self.ff_dim, self.dropout_rate = int(n_heads), int(ff_dim), float(dropout_rate)
+        self.image_size = (int(image_size[0]), int(image_size[1]))
+        self.classes, self.include_top, self.feature_dim = int(classes), bool(include_top), feature_dim
+        self.pooling, self.norm_epsilon, self.norm_mode = pooling, float(norm_epsilon), norm_mode
+        if self.patch_dim % self.n_heads:
+            raise ValueError("patch_dim must be divisible by n_heads")
+        self.head_dim = self.patch_dim // self.n_heads
+        self.grid = (self.image_size[0] // self.patch_size, self.image_size[1] // self.patch_size)
+        self.n_patches = self.grid[0] * self.grid[1]
+        self.n_tokens = self.n_patches + 1
+        self.patch_k = self.patch_size * self.patch_size * 3
+
+    def as_oracle_cfg(self):
+        return {"patch_size": self.patch_size, "n_encoder_layers": self.n_encoder_layers, "n_heads": self.n_heads,
+                "dropout_rate": self.dropout_rate, "norm_epsilon": self.norm_epsilon, "pooling": self.pooling}
+
+
+class ParamSpec:
+    __slots__ = ("name", "shape", "offset", "size", "matrix", "decay")
+
+    def __init__(self, name, shape, offset, matrix, decay):
+        self.name, self.shape, self.offset, self.matrix, self.decay = name, tuple(shape), offset, matrix, decay
+        self.size = int(np.prod(shape))
+
+
+def build_param_table(cfg, decay_fn=None):
+    """Internal parameter list in backward-completion order, with 1024-aligned offsets.
+    Returns (specs, total_elements, bucket_ranges) — bucket k is the slice whose gradients are
+    final after stage k of backward (stage 0 = heads + final norm, 1..L = blocks L-1..0, L+1 = embeddings)."""
+    d, ff, n, kp = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens, cfg.patch_k
+    specs, buckets = [], []
+    off = 0
+
+    def add(name, shape, matrix):
+        nonlocal off
+        decay = True if decay_fn is None else bool(decay_fn(name))
+        s = ParamSpec(name, shape, off, matrix, decay)
+        specs.append(s)
+        off = _round_up(off + s.size, ALIGN)
+
+    start = off
+    if cfg.include_top:
+        cpad = _round_up(cfg.classes, 64)
+        in_dim = cfg.feature_dim or d
+        add("predictions/kernel", (in_dim, cpad), True)
+        add("predictions/bias", (cpad,), False)
+    if cfg.feature_dim:
+        add("feature/kernel", (d, cfg.feature_dim), True)
+        add("feature/bias", (cfg.feature_dim,), False)
+    add("encoder/norm/gamma", (d,), False)
+    add("encoder/norm/beta", (d,), False)
+    buckets.append((start, off))
+    for i in reversed(range(cfg.n_encoder_layers)):
+        start = off
+        p = "encoder/layer_%d/" % i
+        add(p + "dense2/kernel", (ff, d), True)
+        add(p + "dense2/bias", (d,), False)
+        add(p + "dense1/kernel", (d, ff), True)
+        add(p + "dense1/bias", (ff,), False)
+        add(p + "norm2/gamma", (d,), False)
+        add(p + "norm2/beta", (d,), False)
+        add(p + "proj/kernel", (d, d), True)
+        add(p + "proj/bias", (d,), False)
+        add(p + "qkv/kernel", (d, 3 * d), True)
+        add(p + "qkv/bias", (3 * d,), False)
+        add(p + "norm1/gamma", (d,), False)
+        add(p + "norm1/beta", (d,), False)
+        buckets.append((start, off))
+    start = off
+    add("pos_embedding/embeddings", (n, d), False)
+    add("add_cls_token/embeddings", (d,), False)
+    add("patch_embeddings/embedding/kernel", (kp, d), True)
+    add("patch_embeddings/embedding/bias", (d,), False)
+    buckets.append((start, off))
+    return specs, off, buckets
+
+
+# ---------------------------------------------------------------------------------------------
+# Keras-layout <-> internal-layout conversion (SURVEY §8b "weight naming / ownership")
+# ---------------------------------------------------------------------------------------------
+def keras_to_internal(kw, cfg):
+    """kw: dict of Keras-named numpy arrays (names as in oracle/vit_ref.py).  Returns internal dict."""
+    d, h, hd = cfg.patch_dim, cfg.n_heads, cfg.head_dim
+    out = {}
+    out["patch_embeddings/embedding/kernel"] = np.asarray(kw["patch_embeddings/embedding/kernel"]).reshape(cfg.patch_k, d)
+    out["patch_embeddings/embedding/bias"] = np.asarray(kw["patch_embeddings/embedding/bias"])
+    out["add_cls_token/embeddings"] = np.asarray(kw["add_cls_token/embeddings"]).reshape(d)
+    out["pos_embedding/embeddings"] = np.asarray(kw["pos_embedding/embeddings"])
+    for i in range(cfg.n_encoder_layers):
+        p = "encoder/layer_%d/" % i
+        a = p + "multi_head_attention/"
+        wq, wk, wv = (np.asarray(kw[a + k]).reshape(d, h * hd) for k in ("w_query", "w_key", "w_value"))
+        bq, bk, bv = (np.asarray(kw[a + k]).reshape(h * hd) for k in ("b_query", "b_key", "b_value"))
+        out[p + "qkv/kernel"] = np.concatenate([wq, wk, wv], axis=1)
+        out[p + "qkv/bias"] = np.concatenate([bq, bk, bv])
+        out[p + "proj/kernel"] = np.asarray(kw[a + "w_projection"]).transpose(0, 2, 1).reshape(h * hd, d)
+        out[p + "proj/bias"] = np.asarray(kw[a + "b_projection"]).reshape(d)
+        for k in ("norm1/gamma", "norm1/beta", "norm2/gamma", "norm2/beta", "dense1/kernel", "dense1/bias", "dense2/kernel", "dense2/bias"):
+            out[p + k] = np.asarray(kw[p + k])
+    out["encoder/norm/gamma"] = np.asarray(kw["encoder/norm/gamma"])
+    out["encoder/norm/beta"] = np.asarray(kw["encoder/norm/beta"])
+    if cfg.feature_dim:
+        out["feature/kernel"] = np.asarray(kw["feature/kernel"])
+        out["feature/bias"] = np.asarray(kw["feature/bias"])
+    if cfg.include_top:
+        cpad = _round_up(cfg.classes, 64)
+        k = np.asarray(kw["predictions/kernel"])
+        kp = np.zeros((k.shape[0], cpad), dtype=np.float32)
+        kp[:, :cfg.classes] = k
+        bp = np.zeros((cpad,), dtype=np.float32)
+        bp[:cfg.classes] = np.asarray(kw["predictions/bias"])
+        out["predictions/kernel"], out["predictions/bias"] = kp, bp
+    return out
+
+
+def internal_to_keras(iw, cfg):
+    d, h, hd = cfg.patch_dim, cfg.n_heads, cfg.head_dim
+    p_ = cfg.patch_size
+    out = {}
+    out["patch_embeddings/embedding/kernel"] = iw["patch_embeddings/embedding/kernel"].reshape(p_, p_, 3, d)
+    out["patch_embeddings/embedding/bias"] = iw["patch_embeddings/embedding/bias"]
+    out["add_cls_token/embeddings"] = iw["add_cls_token/embeddings"].reshape(1, d)
+    out["pos_embedding/embeddings"] = iw["pos_embedding/embeddings"]
+    for i in range(cfg.n_encoder_layers):
+        p = "encoder/layer_%d/" % i
+        a = p + "multi_head_attention/"
+        w = iw[p + "qkv/kernel"]
+        b = iw[p + "qkv/bias"]
+        for j, nm in enumerate(("query", "key", "value")):
+            out[a + "w_" + nm] = w[:, j * d:(j + 1) * d].reshape(d, h, hd)
+            out[a + "b_" + nm] = b[j * d:(j + 1) * d].reshape(h, 1, hd)
+        out[a + "w_projection"] = iw[p + "proj/kernel"].reshape(h, hd, d).transpose(0, 2, 1)
+        out[a + "b_projection"] = iw[p + "proj/bias"].reshape(1, d)
+        for k in ("norm1/gamma", "norm1/beta", "norm2/gamma", "norm2/beta", "dense1/kernel", "dense1/bias", "dense2/kernel", "dense2/bias"):
+            out[p + k] = iw[p + k]
+    out["encoder/norm/gamma"] = iw["encoder/norm/gamma"]
+    out["encoder/norm/beta"] = iw["encoder/norm/beta"]
+    if cfg.feature_dim:
+        out["feature/kernel"], out["feature/bias"] = iw["feature/kernel"], iw["feature/bias"]
+    if cfg.include_top:
+        out["predictions/kernel"] = iw["predictions/kernel"][:, :cfg.classes]
+        out["predictions/bias"] = iw["predictions/bias"][:cfg.classes]
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def init_keras_weights(cfg, seed=1234):
+    """Random initial weights exactly as the reference's initialisers prescribe (glorot-uniform dense /
+    attention kernels, zero biases, TruncatedNormal(0.02) cls / pos, LayerNorm ones/zeros)."""
+    from . import initializers as I
+    I.set_seed(seed)
+    d, h, hd, ff, p = cfg.patch_dim, cfg.n_heads, cfg.head_dim, cfg.ff_dim, cfg.patch_size
+    tn = I.TruncatedNormal(stddev=0.02)
+    kw = {"patch_embeddings/embedding/kernel": I.glorot_uniform((p, p, 3, d)), "patch_embeddings/embedding/bias": I.zeros((d,)),
+          "add_cls_token/embeddings": tn((1, d)), "pos_embedding/embeddings": tn((cfg.n_tokens, d))}
+    for i in range(cfg.n_encoder_layers):
+        pre = "encoder/layer_%d/" % i
+        a = pre + "multi_head_attention/"
+        kw[a + "w_query"], kw[a + "b_query"] = I.glorot_uniform((d, h, hd)), I.zeros((h, 1, hd))
+        kw[a + "w_value"], kw[a + "b_value"] = I.glorot_uniform((d, h, hd)), I.zeros((h, 1, hd))
+        kw[a + "w_key"], kw[a + "b_key"] = I.glorot_uniform((d, h, hd)), I.zeros((h, 1, hd))
+        kw[a + "w_projection"], kw[a + "b_projection"] = I.glorot_uniform((h, d, hd)), I.zeros((1, d))
+        kw[pre + "norm1/gamma"], kw[pre + "norm1/beta"] = I.ones((d,)), I.zeros((d,))
+        kw[pre + "dense1/kernel"], kw[pre + "dense1/bias"] = I.glorot_uniform((d, ff)), I.zeros((ff,))
+        kw[pre + "dense2/kernel"], kw[pre + "dense2/bias"] = I.glorot_uniform((ff, d)), I.zeros((d,))
+        kw[pre + "norm2/gamma"], kw[pre + "norm2/beta"] = I.ones((d,)), I.zeros((d,))
+    kw["encoder/norm/gamma"], kw["encoder/norm/beta"] = I.ones((d,)), I.zeros((d,))
+    if cfg.feature_dim:
+        kw["feature/kernel"], kw["feature/bias"] = I.glorot_uniform((d, cfg.feature_dim)), I.zeros((cfg.feature_dim,))
+    if cfg.include_top:
+        kw["predictions/kernel"] = I.glorot_uniform((cfg.feature_dim or d, cfg.classes))
+        kw["predictions/bias"] = I.zeros((cfg.classes,))
+    return kw
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel gradient exchange: device-agnostic so gloo/CPU tests cover it
+# ---------------------------------------------------------------------------------------------
+class GradBucketReducer:
+    """All-reduces contiguous slices of a flat gradient buffer as soon as backward marks them final.
+    One logical all-reduce (sum) per step, issued as len(buckets) asynchronous collectives so the
+    exchange of block l overlaps the backward of blocks < l; `finish()` waits for all of them.
+    Averaging (x 1/world) is folded into the optimizer's grad_scale."""
+
+    def __init__(self, flat_grad, buckets, process_group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.flat = flat_grad
+        self.buckets = list(buckets)
+        self.group = process_group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.world = dist.get_world_size(process_group) if self.active else 1
+        self.handles = []
+
+    def bucket_ready(self, k):
+        if not self.active:
+            return
+        lo, hi = self.buckets[k]
+        if hi > lo:
+            self.handles.append(self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+
+# ---------------------------------------------------------------------------------------------
+class ViTEngine:
+    def __init__(self, cfg, batch_size, device=None, training=True, seed=0, decay_fn=None, process_group=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ViTEngine needs an MI355X (torch.cuda is not available); there is no CPU fallback")
+        self.cfg, self.B, self.training, self.seed = cfg, int(batch_size), bool(training), int(seed)
+        self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if cfg.head_dim != 64:
+            raise ValueError("attention kernels are built for head_dim 64 (all reference ViT configs), got %d" % cfg.head_dim)
+        if cfg.pooling != "cls":
+            raise ValueError("the engine implements pooling='cls' (vision_transformer.py:182-189); got %r" % (cfg.pooling,))
+        self.specs, self.n_params_padded, self.buckets = build_param_table(cfg, decay_fn)
+        self.by_name = {s.name: s for s in self.specs}
+        dev, f32, bf = self.dev, torch.float32, torch.bfloat16
+        nflat = self.n_params_padded
+        self.P = torch.zeros(nflat, dtype=f32, device=dev)
+        self.Pb = torch.zeros(nflat, dtype=bf, device=dev)    # [K][N] images (dgrad B operand)
+        self.Pbt = torch.zeros(nflat, dtype=bf, device=dev)   # [N][K] images (forward B operand)
+        if training:
+            self.G = torch.zeros(nflat, dtype=f32, device=dev)
+            self.Mo = torch.zeros(nflat, dtype=f32, device=dev)
+            self.Vo = torch.zeros(nflat, dtype=f32, device=dev)
+            flags = np.zeros(nflat // ALIGN, dtype=np.uint8)
+            for s in self.specs:
+                flags[s.offset // ALIGN:_round_up(s.offset + s.size, ALIGN) // ALIGN] = 1 if s.decay else 0
+            self.decay_flags = torch.as_tensor(flags, device=dev)
+            self.reducer = GradBucketReducer(self.G, self.buckets, process_group)
+        mats = [s for s in self.specs if s.matrix]
+        desc = np.array([[s.offset, s.offset, s.shape[0], s.shape[1]] for s in mats], dtype=np.int64)
+        self.ct_desc = torch.as_tensor(desc, device=dev)
+        self.ct_n = len(mats)
+        self.ct_tiles = max(((s.shape[0] + 63) // 64) * ((s.shape[1] + 63) // 64) for s in mats)
+        self.opt_step = 0
+        self._alloc_activations()
+
+    # ---- views --------------------------------------------------------------------------
+    def _v(self, buf, name):
+        s = self.by_name[name]
+        return buf[s.offset:s.offset + s.size].view(*s.shape)
+
+    def p(self, name):
+        return self._v(self.P, name)
+
+    def g(self, name):
+        return self._v(self.G, name)
+
+    def wb(self, name):   # bf16 [K][N]
+        return self._v(self.Pb, name)
+
+    def wbt(self, name):  # bf16 [N][K]
+        s = self.by_name[name]
+        return self.Pbt[s.offset:s.offset + s.size].view(s.shape[1], s.shape[0])
+
+    # ---- weights in / out ------------------------------------------------------------------
+    def load_keras_weights(self, kw):
+        iw = keras_to_internal(kw, self.cfg)
+        host = np.zeros(self.n_params_padded, dtype=np.float32)
+        for s in self.specs:
+            arr = np.asarray(iw[s.name], dtype=np.float32)
+            if arr.shape != s.shape:
+                raise ValueError("weight %s: expected shape %s, got %s" % (s.name, s.shape, arr.shape))
+            host[s.offset:s.offset + s.size] = arr.reshape(-1)
+        self.P.copy_(torch.from_numpy(host))
+        self.refresh_operands()
+
+    def export_keras_weights(self):
+        host = self.P.detach().cpu().numpy()
+        iw = {s.name: host[s.offset:s.offset + s.size].reshape(s.shape).copy() for s in self.specs}
+        return internal_to_keras(iw, self.cfg)
+
+    def export_keras_grads(self):
+        host = self.G.detach().cpu().numpy()
+        iw = {s.name: host[s.offset:s.offset + s.size].reshape(s.shape).copy() for s in self.specs}
+        return internal_to_keras(iw, self.cfg)
+
+    def refresh_operands(self):
+        """fp32 master -> bf16 [K][N] and [N][K] images of every matrix (one launch)."""
+        K.cast_transpose(self.P, self.Pb, self.Pbt, self.ct_desc, self.ct_n, self.ct_tiles)
+
+    # ---- buffers --------------------------------------------------------------------------
+    def _alloc_activations(self):
+        cfg, B, dev = self.cfg, self.B, self.dev
+        f32, bf = torch.float32, torch.bfloat16
+        d, ff, n = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens
+        self.M = B * n
+        self.Mp = _round_up(self.M, 256)
+        self.Bp = _round_up(B, 64)
+        self.Mpatch = B * cfg.n_patches
+        self.Mpatch_p = _round_up(self.Mpatch, 64)
+        Mp = self.Mp
+        L = cfg.n_encoder_layers
+        nsave = L if self.training else 1
+        z = lambda *shape, dtype=bf: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        self.patches = z(self.Mpatch_p, cfg.patch_k)
+        self.xs = [z(Mp, d, dtype=f32) for _ in range((L + 1) if self.training else 2)]
+        self.acts = []
+        for _ in range(nsave):
+            self.acts.append({
+                "h1": z(Mp, d), "mean1": z(Mp, dtype=f32), "rstd1": z(Mp, dtype=f32), "qkv": z(Mp, 3 * d), "o": z(Mp, d),
+                "lse": z(B * cfg.n_heads * n, dtype=f32), "xmid": z(Mp, d, dtype=f32), "h2": z(Mp, d), "mean2": z(Mp, dtype=f32),
+                "rstd2": z(Mp, dtype=f32), "a1": z(Mp, ff), "u": z(Mp, ff)})
+        self.hf = z(self.Bp, d)
+        self.meanf, self.rstdf = z(self.Bp, dtype=f32), z(self.Bp, dtype=f32)
+        if cfg.include_top:
+            self.cpad = _round_up(cfg.classes, 64)
+            self.logits = z(self.Bp, self.cpad, dtype=f32)
+        self.loss_vec = z(self.Bp, dtype=f32)
+        if self.training:
+            self.dlogits = z(self.Bp, self.cpad)
+            self.dhf = z(self.Bp, d)
+            self.dx = z(Mp, d, dtype=f32)
+            self.dz = z(Mp, d)
+            self.da1 = z(Mp, ff)
+            self.dh = z(Mp, d)
+            self.do = z(Mp, d)
+            self.dqkv = z(Mp, 3 * d)
+            self.dpatch = z(self.Mpatch_p, d)
+            self.labels = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+
+    def activation_bytes(self):
+        tot = 0
+        for t in [self.patches, self.hf] + self.xs + [v for a in self.acts for v in a.values()]:
+            tot += t.numel() * t.element_size()
+        return tot
+
+    # ---- forward --------------------------------------------------------------------------
+    def _keys(self, training):
+        cfg = self.cfg
+        rate = cfg.dropout_rate if training else 0.0
+        step = self.opt_step
+        return rate, (lambda site: rng.site_key(self.seed, step, site))
+
+    def embed(self, images_u8, training):
+        """normalise + patchify + patch-embedding GEMM (+bias +pos, dropout) + cls row -> xs[0]."""
+        cfg = self.cfg
+        rate, key = self._keys(training)
+        if tuple(images_u8.shape) != (self.B, cfg.image_size[0], cfg.image_size[1], 3):
+            raise ValueError("expected images of shape %s, got %s" % ((self.B,) + cfg.image_size + (3,), tuple(images_u8.shape)))
+        K.normalize_patchify(images_u8, cfg.patch_size, cfg.norm_mode, out=self.patches)
+        x0 = self.xs[0]
+        K.gemm_nt(self.patches, self.wbt("patch_embeddings/embedding/kernel"), x0, m=self.Mpatch,
+                  bias=self.p("patch_embeddings/embedding/bias"), epilogue=K.EPI_PATCH, resid=self.p("pos_embedding/embeddings"),
+                  period=cfg.n_patches, drop_rate=rate, drop_key=key(rng.SITE_EMBED))
+        K.cls_row(x0, self.p("add_cls_token/embeddings"), self.p("pos_embedding/embeddings"), self.B, cfg.n_tokens, cfg.patch_dim,
+                  drop_rate=rate, drop_key=key(rng.SITE_EMBED))
+        return x0
+
+    def block_forward(self, l, x_in, x_out, a, training):
+        cfg = self.cfg
+        rate, key = self._keys(training)
+        d, M = cfg.patch_dim, self.M
+        pre = "encoder/layer_%d/" % l
+        K.layernorm_fwd(x_in, d, self.p(pre + "norm1/gamma"), self.p(pre + "norm1/beta"), a["h1"], a["mean1"], a["rstd1"], M, d,
+                        cfg.norm_epsilon)
+        K.gemm_nt(a["h1"], self.wbt(pre + "qkv/kernel"), a["qkv"], m=M, bias=self.p(pre + "qkv/bias"))
+        K.attention_fwd(a["qkv"], a["o"], a["lse"], self.B, cfg.n_tokens, cfg.n_heads, cfg.head_dim, rate, key(rng.site_attn(l)))
+        K.gemm_nt(a["o"], self.wbt(pre + "proj/kernel"), a["xmid"], m=M, bias=self.p(pre + "proj/bias"), epilogue=K.EPI_RESID,
+                  resid=x_in, drop_rate=rate, drop_key=key(rng.site_proj(l)))
+        K.layernorm_fwd(a["xmid"], d, self.p(pre + "norm2/gamma"), self.p(pre + "norm2/beta"), a["h2"], a["mean2"], a["rstd2"], M, d,
+                        cfg.norm_epsilon)
+        K.gemm_nt(a["h2"], self.wbt(pre + "dense1/kernel"), a["u"], m=M, bias=self.p(pre + "dense1/bias"), epilogue=K.EPI_GELU,
+                  aux=a["a1"])
+        K.gemm_nt(a["u"], self.wbt(pre + "dense2/kernel"), x_out, m=M, bias=self.p(pre + "dense2/bias"), epilogue=K.EPI_RESID,
+                  resid=a["xmid"], drop_rate=rate, drop_key=key(rng.site_mlp(l)))
+
+    def forward(self, images_u8, training=None):
+        """Returns logits fp32 [B, classes] (a view of the padded logits buffer)."""
+        training = self.training if training is None else training
+        cfg = self.cfg
+        L = cfg.n_encoder_layers
+        x = self.embed(images_u8, training)
+        for l in range(L):
+            if self.training:
+                x_out, a = self.xs[l + 1], self.acts[l]
+            else:
+                x_out, a = self.xs[(l + 1) & 1], self.acts[0]
+            self.block_forward(l, x, x_out, a, training)
+            x = x_out
+        self.x_final = x
+        d, n = cfg.patch_dim, cfg.n_tokens
+        # final LayerNorm only where it is consumed: the cls rows (row stride n*d)
+        K.layernorm_fwd(x, n * d, self.p("encoder/norm/gamma"), self.p("encoder/norm/beta"), self.hf, self.meanf, self.rstdf, self.B, d,
+                        cfg.norm_epsilon)
+        if cfg.feature_dim:
+            raise NotImplementedError("feature (tanh) head is not built into the engine yet")
+        if not cfg.include_top:
+            return self.hf[:self.B]
+        K.gemm_nt(self.hf, self.wbt("predictions/kernel"), self.logits, m=self.B, bias=self.p("predictions/bias"))
+        return self.logits[:self.B, :cfg.classes]
+
+    def loss(self, labels):
+        """Sparse softmax cross-entropy from logits, mean over the batch; also fills dlogits when training."""
+        self.labels[:self.B].copy_(labels.to(torch.int32))
+        K.softmax_ce(self.logits, self.labels, self.loss_vec, self.dlogits if self.training else None, self.cfg.classes, 1.0 / self.B)
+        return self.loss_vec[:self.B]
+
+    # ---- backward -------------------------------------------------------------------------
+    def backward(self):
+        cfg = self.cfg
+        rate, key = self._keys(True)
+        d, ff, n, M, Mp = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens, self.M, self.Mp
+        L = cfg.n_encoder_layers
+        self.G.zero_()
+        self.dx.zero_()
+        # head + final norm
+        K.gemm_tn(self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp)
+        K.colsum(self.dlogits, self.g("predictions/bias"), m=self.B)
+        K.gemm_nt(self.dlogits, self.wb("predictions/kernel"), self.dhf, m=self.B)
+        K.layernorm_bwd(self.dhf, self.x_final, n * d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, n * d, False,
+                        self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
+        self.reducer.bucket_ready(0)
+        for l in reversed(range(L)):
+            a = self.acts[l]
+            pre = "encoder/layer_%d/" % l
+            # MLP branch
+            K.dropout_bwd(self.dx, self.dz, M, d, rate, key(rng.site_mlp(l)))
+            K.gemm_tn(a["u"], self.dz, self.g(pre + "dense2/kernel"), m=Mp)
+            K.colsum(self.dz, self.g(pre + "dense2/bias"), m=M)
+            K.gemm_nt(self.dz, self.wb(pre + "dense2/kernel"), self.da1, m=M, epilogue=K.EPI_DGELU, aux=a["a1"])
+            K.gemm_tn(a["h2"], self.da1, self.g(pre + "dense1/kernel"), m=Mp)
+            K.colsum(self.da1, self.g(pre + "dense1/bias"), m=M)
+            K.gemm_nt(self.da1, self.wb(pre + "dense1/kernel"), self.dh, m=M)
+            K.layernorm_bwd(self.dh, a["xmid"], d, a["mean2"], a["rstd2"], self.p(pre + "norm2/gamma"), self.dx, d, True,
+                            self.g(pre + "norm2/gamma"), self.g(pre + "norm2/beta"), M, d)
+            # attention branch
+            K.dropout_bwd(self.dx, self.dz, M, d, rate, key(rng.site_proj(l)))
+            K.gemm_tn(a["o"], self.dz, self.g(pre + "proj/kernel"), m=Mp)
+            K.colsum(self.dz, self.g(pre + "proj/bias"), m=M)
+            K.gemm_nt(self.dz, self.wb(pre + "proj/kernel"), self.do, m=M)
+            K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], self.dqkv, self.B, n, cfg.n_heads, cfg.head_dim, rate,
+                            key(rng.site_attn(l)))
+            K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp)
+            K.colsum(self.dqkv, self.g(pre + "qkv/bias"), m=M)
+            K.gemm_nt(self.dqkv, self.wb(pre + "qkv/kernel"), self.dh, m=M)
+            K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
+                            self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d)
+            self.reducer.bucket_ready(L - l)
+        # embedding stage
+        K.embed_bwd(self.dx, self.dpatch, self.g("pos_embedding/embeddings"), self.g("add_cls_token/embeddings"), self.B, n, d, rate,
+                    key(rng.SITE_EMBED))
+        K.gemm_tn(self.patches, self.dpatch, self.g("patch_embeddings/embedding/kernel"), m=self.Mpatch_p)
+        K.colsum(self.dpatch, self.g("patch_embeddings/embedding/bias"), m=self.Mpatch)
+        self.reducer.bucket_ready(L + 1)
+
+    # ---- optimizer ------------------------------------------------------------------------
+    def adamw_step(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, weight_decay=0.0):
+        """chambers.optimizers.AdamW semantics (decay first, wd not scaled by lr, keras Adam epsilon-hat form)."""
+        self.reducer.finish()
+        self.opt_step += 1
+        t = self.opt_step
+        b1, b2 = np.float32(beta_1), np.float32(beta_2)
+        lr_t = np.float32(learning_rate) * np.sqrt(np.float32(1.0) - np.power(b2, np.float32(t))) / (np.float32(1.0) - np.power(b1, np.float32(t)))
+        K.adamw(self.P, self.G, self.Mo, self.Vo, self.decay_flags, float(lr_t), beta_1, beta_2, epsilon, weight_decay,
+                self.reducer.grad_scale)
+        self.refresh_operands()
+
+    def train_step(self, images_u8, labels, **opt):
+        """augmented uint8 batch -> loss vector; runs forward, loss, backward, gradient exchange, AdamW."""
+        self.forward(images_u8, training=True)
+        loss = self.loss(labels)
+        self.backward()
+        self.adamw_step(**opt)
+        return loss

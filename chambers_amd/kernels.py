@@ -1,0 +1,236 @@
+"""Host-side launch wrappers: torch tensors in, C-ABI calls out (one function per entry of
+include/chambers_hip.h).  torch supplies device memory and the stream, nothing else; every
+function raises if its tensors are not on the GPU (no CPU fallback on the product path).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (EPI_DGELU, EPI_GELU, EPI_NONE, EPI_PATCH, EPI_RESID, NORM_CAFFE, NORM_TF, NORM_TORCH, OUT_BF16,  # noqa: F401
+                   OUT_F32, PW_BRIGHTNESS, PW_COLOR, PW_CONTRAST, PW_INVERT, PW_POSTERIZE, PW_SOLARIZE, PW_SOLARIZE_ADD)
+
+NORM_MODES = {"caffe": NORM_CAFFE, "tf": NORM_TF, "torch": NORM_TORCH}
+
+
+def _s():
+    return _lib.stream_ptr()
+
+
+def _u8_nhwc(x):
+    _lib.require_gpu(x)
+    if x.dtype != torch.uint8 or x.dim() != 4:
+        raise ValueError("expected a uint8 NHWC tensor of rank 4, got %s %s" % (x.dtype, tuple(x.shape)))
+    return x.contiguous()
+
+
+# ------------------------------------------------------------------ augmentation
+def aug_pointwise(x, op, factor=0.0, i0=0, i1=0, out=None):
+    x = _u8_nhwc(x)
+    if op == PW_COLOR and x.shape[-1] != 3:
+        raise ValueError("Color needs 3 channels")
+    out = torch.empty_like(x) if out is None else out
+    _lib.call("chb_aug_pointwise", _lib.ptr(x), _lib.ptr(out), x.numel(), int(op), float(factor), int(i0), int(i1), _s())
+    return out
+
+
+def aug_affine(x, transform, fill=0):
+    """transform: 8 floats (shared by the batch) or a float32 device tensor [B,8]."""
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    out = torch.empty_like(x)
+    if isinstance(transform, torch.Tensor):
+        _lib.require_gpu(transform)
+        t = transform.to(torch.float32).contiguous()
+        if t.numel() not in (8, 8 * b):
+            raise ValueError("transforms must have 8 or B*8 elements")
+        _lib.call("chb_aug_affine", _lib.ptr(x), _lib.ptr(out), b, h, w, c, None, _lib.ptr(t), int(t.numel() == 8 * b), int(fill), _s())
+    else:
+        t = np.ascontiguousarray(np.asarray(transform, dtype=np.float32).reshape(8))
+        _lib.call("chb_aug_affine", _lib.ptr(x), _lib.ptr(out), b, h, w, c, t.ctypes.data_as(ctypes.c_void_p), None, 0, int(fill), _s())
+    return out
+
+
+def aug_cutout(x, centers, mask_size, value=0):
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    if int(mask_size) % 2 != 0:
+        raise ValueError("mask_size should be divisible by 2")
+    if not isinstance(centers, torch.Tensor):
+        centers = torch.as_tensor(np.asarray(centers, dtype=np.int32).reshape(b, 2), device=x.device)
+    centers = centers.to(torch.int32).contiguous()
+    _lib.require_gpu(centers)
+    out = torch.empty_like(x)
+    _lib.call("chb_aug_cutout", _lib.ptr(x), _lib.ptr(out), b, h, w, c, _lib.ptr(centers), int(mask_size), int(value), _s())
+    return out
+
+
+def aug_autocontrast(x):
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    ws = torch.empty(max(b * c * 2, 1), dtype=torch.int32, device=x.device)
+    out = torch.empty_like(x)
+    _lib.call("chb_aug_autocontrast", _lib.ptr(x), _lib.ptr(out), b, h, w, c, _lib.ptr(ws), _s())
+    return out
+
+
+def aug_equalize(x):
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    ws = torch.empty(max(b * c * 256, 1), dtype=torch.int32, device=x.device)
+    out = torch.empty_like(x)
+    _lib.call("chb_aug_equalize", _lib.ptr(x), _lib.ptr(out), b, h, w, c, _lib.ptr(ws), _s())
+    return out
+
+
+def aug_sharpness(x, factor):
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    out = torch.empty_like(x)
+    _lib.call("chb_aug_sharpness", _lib.ptr(x), _lib.ptr(out), b, h, w, c, float(factor), _s())
+    return out
+
+
+def normalize(x, mode):
+    _lib.require_gpu(x)
+    if mode not in NORM_MODES:
+        raise ValueError("Unknown mode " + str(mode))
+    x = x.contiguous()
+    c = x.shape[-1]
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    n_pixels = x.numel() // c
+    if x.dtype == torch.uint8:
+        _lib.call("chb_normalize_u8", _lib.ptr(x), _lib.ptr(out), n_pixels, c, NORM_MODES[mode], _s())
+    else:
+        x = x.to(torch.float32)
+        _lib.call("chb_normalize_f32", _lib.ptr(x), _lib.ptr(out), n_pixels, c, NORM_MODES[mode], _s())
+    return out
+
+
+def normalize_patchify(x, patch, mode="tf", out=None):
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    if c != 3:
+        raise ValueError("patchify expects RGB input")
+    rows = b * (h // patch) * (w // patch)
+    if out is None:
+        out = torch.empty((rows, patch * patch * 3), dtype=torch.bfloat16, device=x.device)
+    _lib.call("chb_normalize_patchify_bf16", _lib.ptr(x), _lib.ptr(out), b, h, w, int(patch), NORM_MODES[mode], _s())
+    return out
+
+
+def patchify_f32(x, patch, out=None):
+    _lib.require_gpu(x)
+    if x.dtype != torch.float32 or x.dim() != 4 or x.shape[-1] != 3:
+        raise ValueError("expected a float32 NHWC RGB tensor")
+    x = x.contiguous()
+    b, h, w, _ = x.shape
+    rows = b * (h // patch) * (w // patch)
+    if out is None:
+        out = torch.empty((rows, patch * patch * 3), dtype=torch.bfloat16, device=x.device)
+    _lib.call("chb_patchify_f32_bf16", _lib.ptr(x), _lib.ptr(out), b, h, w, int(patch), _s())
+    return out
+
+
+# ------------------------------------------------------------------ dropout mask
+def dropout_mask(n, rate, key, device="cuda"):
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    _lib.call("chb_dropout_mask", _lib.ptr(out), n, float(rate), ctypes.c_uint32(int(key)), _s())
+    return out
+
+
+# ------------------------------------------------------------------ ViT block
+def gemm_nt(a, b, out, m=None, bias=None, epilogue=EPI_NONE, aux=None, resid=None, period=0, drop_rate=0.0, drop_key=0):
+    """out[M,N] = epi(a[M,K] . b[N,K]^T); a, b bf16 2-D (row stride taken from the tensors)."""
+    _lib.require_gpu(a, b, out, bias, aux, resid)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise ValueError("gemm operands must be bfloat16")
+    m = a.shape[0] if m is None else m
+    n, k = b.shape[0], b.shape[1]
+    if a.shape[1] != k:
+        raise ValueError("inner dimensions differ: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    out_dtype = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+    _lib.call("chb_gemm_nt", _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), _lib.ptr(out), out.stride(0), int(m), int(n), int(k),
+              _lib.ptr(bias), int(epilogue), out_dtype, _lib.ptr(aux), aux.stride(0) if aux is not None else 0, _lib.ptr(resid),
+              resid.stride(0) if resid is not None else 0, int(period), float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+    return out
+
+
+def gemm_tn(x, dy, dw, m=None):
+    """dw[Kd,Nd] += x[M,Kd]^T . dy[M,Nd] (fp32 accumulate)."""
+    _lib.require_gpu(x, dy, dw)
+    m = x.shape[0] if m is None else m
+    _lib.call("chb_gemm_tn", _lib.ptr(x), x.stride(0), _lib.ptr(dy), dy.stride(0), _lib.ptr(dw), dw.stride(0), int(m), x.shape[1], dy.shape[1],
+              _s())
+    return dw
+
+
+def layernorm_fwd(x, x_stride, gamma, beta, y, mean, rstd, m, d, eps):
+    _lib.require_gpu(x, gamma, beta, y, mean, rstd)
+    _lib.call("chb_layernorm_fwd", _lib.ptr(x), int(x_stride), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd),
+              int(m), int(d), float(eps), _s())
+    return y
+
+
+def layernorm_bwd(dy, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, m, d):
+    _lib.require_gpu(dy, x, mean, rstd, gamma, dx, dgamma, dbeta)
+    _lib.call("chb_layernorm_bwd", _lib.ptr(dy), _lib.ptr(x), int(x_stride), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dx),
+              int(dx_stride), int(bool(accumulate)), _lib.ptr(dgamma), _lib.ptr(dbeta), int(m), int(d), _s())
+    return dx
+
+
+def attention_fwd(qkv, o, lse, b, n, h, hd, drop_rate=0.0, drop_key=0):
+    _lib.require_gpu(qkv, o, lse)
+    _lib.call("chb_attention_fwd", _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse), int(b), int(n), int(h), int(hd), float(drop_rate),
+              ctypes.c_uint32(int(drop_key)), _s())
+    return o
+
+
+def attention_bwd(qkv, o, d_o, lse, dqkv, b, n, h, hd, drop_rate=0.0, drop_key=0):
+    _lib.require_gpu(qkv, o, d_o, lse, dqkv)
+    _lib.call("chb_attention_bwd", _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(d_o), _lib.ptr(lse), _lib.ptr(dqkv), int(b), int(n), int(h), int(hd),
+              float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+    return dqkv
+
+
+def cls_row(x, cls, pos, b, n, d, drop_rate=0.0, drop_key=0):
+    _lib.require_gpu(x, cls, pos)
+    _lib.call("chb_cls_row", _lib.ptr(x), _lib.ptr(cls), _lib.ptr(pos), int(b), int(n), int(d), float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+
+
+def embed_bwd(dx, dpatch, dpos, dcls, b, n, d, drop_rate=0.0, drop_key=0):
+    _lib.require_gpu(dx, dpatch, dpos, dcls)
+    _lib.call("chb_embed_bwd", _lib.ptr(dx), _lib.ptr(dpatch), _lib.ptr(dpos), _lib.ptr(dcls), int(b), int(n), int(d), float(drop_rate),
+              ctypes.c_uint32(int(drop_key)), _s())
+
+
+def dropout_bwd(dy, dz, m, n, drop_rate=0.0, drop_key=0):
+    _lib.require_gpu(dy, dz)
+    _lib.call("chb_dropout_bwd_bf16", _lib.ptr(dy), dy.stride(0), _lib.ptr(dz), int(m), int(n), float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+    return dz
+
+
+def colsum(x, out, m=None):
+    _lib.require_gpu(x, out)
+    m = x.shape[0] if m is None else m
+    _lib.call("chb_colsum_bf16", _lib.ptr(x), x.stride(0), _lib.ptr(out), int(m), x.shape[1], _s())
+    return out
+
+
+def softmax_ce(logits, labels, loss, dlogits, classes, grad_scale):
+    _lib.require_gpu(logits, labels, loss, dlogits)
+    _lib.call("chb_softmax_ce", _lib.ptr(logits), logits.stride(0), _lib.ptr(labels), _lib.ptr(loss), _lib.ptr(dlogits),
+              dlogits.stride(0) if dlogits is not None else 0, logits.shape[0], int(classes), float(grad_scale), _s())
+    return loss
+
+
+def cast_transpose(src, dst, dst_t, desc, n_desc, max_tiles):
+    _lib.require_gpu(src, dst, dst_t, desc)
+    _lib.call("chb_cast_transpose", _lib.ptr(src), _lib.ptr(dst), _lib.ptr(dst_t), _lib.ptr(desc), int(n_desc), int(max_tiles), _s())
+
+
+def adamw(p, g, m, v, flags, lr_t, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    _lib.require_gpu(p, g, m, v, flags)
+    _lib.call("chb_adamw", _lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(flags), p.numel(), float(lr_t), float(beta1), float(beta2),
+              float(eps), float(weight_decay), float(grad_scale), _s())

@@ -1,0 +1,175 @@
+/* chambers_hip.h — C ABI of libchambers_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the ONE hot path of chjort/chambers this build accelerates:
+ * RandAugment/AutoAugment -> ImageNetNormalization -> VisionTransformer forward/backward
+ * -> AdamW.  The reference has no FFI of its own (it is pure Python over TensorFlow); the
+ * interface each entry replaces is therefore the TF/Keras/TFA op sequence issued by the
+ * cited reference lines (paths relative to /root/reference/chambers/).  INTEGRATION.md
+ * shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - the caller owns all memory (inputs, outputs, workspaces); the library never
+ *     allocates, frees or synchronises;
+ *   - every entry is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant
+ *     and thread-safe for distinct streams; randomness is passed in (decision values or
+ *     a 32-bit dropout site key), never drawn from hidden state;
+ *   - return value: 0 = ok, CHB_EINVAL (-1) bad argument, CHB_ELAUNCH (-2) launch failure,
+ *     CHB_EUNSUPPORTED (-3) shape outside what the kernels are built for.  Nothing throws.
+ *   - bf16 tensors are raw uint16 bit patterns (void*); images are uint8 NHWC; token
+ *     matrices are row-major [rows, ld].
+ */
+#ifndef CHAMBERS_HIP_H
+#define CHAMBERS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pointwise op ids for chb_aug_pointwise */
+#define CHB_PW_INVERT 0       /* augmentations/image_augmentations.py:112-113 */
+#define CHB_PW_POSTERIZE 1    /* :171-174   i0 = shift (8 - bits, clamped to 7) */
+#define CHB_PW_SOLARIZE 2     /* :192-193   i0 = threshold (may be 256) */
+#define CHB_PW_SOLARIZE_ADD 3 /* :212-215   i0 = threshold, i1 = addition */
+#define CHB_PW_BRIGHTNESS 4   /* :283-285   factor */
+#define CHB_PW_CONTRAST 5     /* :253-265   factor, i0 = degenerate constant (host: pixels/256 clipped) */
+#define CHB_PW_COLOR 6        /* :233-235   factor; 3 channels */
+
+#define CHB_NORM_CAFFE 0 /* :647-650 */
+#define CHB_NORM_TF 1    /* :659-665 */
+#define CHB_NORM_TORCH 2 /* :652-657 */
+
+/* GEMM epilogue modes (chb_gemm_nt) */
+#define CHB_EPI_NONE 0   /* C = acc (+bias) */
+#define CHB_EPI_GELU 1   /* aux = bf16(acc+bias); C = gelu(acc+bias)      layers/transformer.py:42-44 */
+#define CHB_EPI_DGELU 2  /* C = acc * gelu'(aux)                          backward of the above */
+#define CHB_EPI_RESID 3  /* C = resid + dropout(acc+bias)                 layers/transformer.py:57-58,69,76 */
+#define CHB_EPI_PATCH 4  /* C[row'] = dropout(acc+bias+pos[1+p])          vision_transformer.py:235-261 */
+
+#define CHB_OUT_BF16 0
+#define CHB_OUT_F32 1
+
+/* ---------------------------------------------------------------- library info */
+int chb_version(void);            /* ABI version, currently 1 */
+const char* chb_build_arch(void); /* "gfx950" */
+
+/* ---------------------------------------------------------------- augmentation (uint8 NHWC) */
+/* Invert / Posterize / Solarize / SolarizeAdd / Brightness / Contrast / Color over a flat
+ * NHWC byte buffer (image_augmentations.py:107-293 + blend :10-49).  in == out allowed. */
+int chb_aug_pointwise(const uint8_t* in, uint8_t* out, int64_t n_bytes, int op, float factor, int i0, int i1,
+                      void* stream);
+
+/* tfa.image.transform / translate / rotate with interpolation="nearest", fill_mode="constant"
+ * (ShearX/ShearY/TranslateX/TranslateY/Rotate, image_augmentations.py:120-160,316-484).
+ * One 8-float projective transform maps OUTPUT (x,y) to INPUT coordinates.  Pass either
+ * transform_host8 (8 floats on the host, shared by the batch, copied into the launch) or
+ * transforms_dev ([B,8] if per_image else [1,8], device). */
+int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, const float* transform_host8,
+                   const float* transforms_dev, int per_image, int fill, void* stream);
+
+/* tfa.image.random_cutout with the per-image centres drawn by the caller: centers_dev is
+ * int32 [B,2] = (cy, cx) (CutOut, image_augmentations.py:488-507). mask_size must be even. */
+int chb_aug_cutout(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, const int32_t* centers_dev, int mask_size,
+                   int value, void* stream);
+
+/* AutoContrast (image_augmentations.py:63-90). workspace: int32 [B*C*2]. */
+int chb_aug_autocontrast(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, int32_t* workspace, void* stream);
+
+/* Equalize -> tfa.image.equalize (image_augmentations.py:94-103). workspace: int32 [B*C*256]. */
+int chb_aug_equalize(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, int32_t* workspace, void* stream);
+
+/* Sharpness -> tfa.image.sharpness (image_augmentations.py:297-312). in != out. */
+int chb_aug_sharpness(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, float factor, void* stream);
+
+/* ImageNetNormalization (image_augmentations.py:621-682), fp32 NHWC output. */
+int chb_normalize_u8(const uint8_t* in, float* out, int64_t n_pixels, int channels, int mode, void* stream);
+int chb_normalize_f32(const float* in, float* out, int64_t n_pixels, int channels, int mode, void* stream);
+
+/* ImageNetNormalization fused with the patch gather of the patch-embedding Conv2D
+ * (vision_transformer.py:235-248,655): uint8 [B,H,W,3] -> bf16 [B*(H/p)*(W/p), p*p*3]. */
+int chb_normalize_patchify_bf16(const uint8_t* in, void* out_bf16, int B, int H, int W, int patch, int mode, void* stream);
+/* Same gather for an already-normalised float32 NHWC batch (the reference model's own input dtype). */
+int chb_patchify_f32_bf16(const float* in, void* out_bf16, int B, int H, int W, int patch, void* stream);
+
+/* ---------------------------------------------------------------- dropout mask (test / tooling) */
+/* out[e] = 1 if element e is kept under (key, rate) else 0 — the mask every fused dropout
+ * site uses (definition: oracle/rng_ref.py; sites: keras Dropout, layers/transformer.py:38,48). */
+int chb_dropout_mask(uint8_t* out, int64_t n, float rate, uint32_t key, void* stream);
+
+/* ---------------------------------------------------------------- ViT block */
+/* C[M,N] = epilogue(A[M,K] . B[N,K]^T): bf16 operands, both K-contiguous, fp32 accumulate on
+ * MFMA (Dense / einsum projections: layers/attention.py:113-125, layers/transformer.py:72-77,
+ * vision_transformer.py:235-283).  bias fp32 [N] or NULL.  out_dtype CHB_OUT_BF16|CHB_OUT_F32.
+ *  GELU : aux (bf16 [M,ld_aux]) receives the pre-activation.
+ *  DGELU: aux is the saved pre-activation.
+ *  RESID: resid fp32 [M,ld_resid] (may alias C); dropout (rate,key) on acc+bias, element
+ *         index row*N+col.
+ *  PATCH: rows are (image b, patch p) = row / period, row % period; written to row
+ *         b*(period+1)+1+p of C; resid = positional table fp32 [period+1, ld_resid];
+ *         dropout element index out_row*N+col.
+ * K % 64 == 0; M, N arbitrary (edges masked); A/B/C 16-byte aligned rows. */
+int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                const float* bias, int epilogue, int out_dtype, void* aux, int64_t ld_aux, const float* resid,
+                int64_t ld_resid, int period, float drop_rate, uint32_t drop_key, void* stream);
+
+/* dW[Kd,Nd] += X[M,Kd]^T . dY[M,Nd]: weight gradient, bf16 operands, fp32 atomic accumulate
+ * into dW (caller zeroes it once per step).  M % 64 == 0 (pad rows must be zero). */
+int chb_gemm_tn(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int M, int Kd, int Nd,
+                void* stream);
+
+/* keras LayerNormalization over the last axis (layers/transformer.py:39,49,283): x fp32 rows at
+ * stride x_stride, y bf16 [M,D]; mean/rstd fp32 [M] saved for backward. D % 4 == 0, D <= 1024. */
+int chb_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* y_bf16,
+                      float* mean, float* rstd, int M, int D, float eps, void* stream);
+/* dx[row] (+)= LN'(dy); dgamma/dbeta fp32 [D] accumulated with atomics (caller zeroes). */
+int chb_layernorm_bwd(const void* dy_bf16, const float* x, int64_t x_stride, const float* mean, const float* rstd,
+                      const float* gamma, float* dx, int64_t dx_stride, int accumulate, float* dgamma, float* dbeta,
+                      int M, int D, void* stream);
+
+/* MultiHeadAttention core (layers/attention.py:7-23,113-125): softmax(QK^T/sqrt(hd)) with
+ * dropout on the probabilities, times V.  qkv bf16 [B*N, 3*H*hd] = [Q heads | K heads | V heads];
+ * o bf16 [B*N, H*hd]; lse fp32 [B,H,N]. hd == 64. Dropout element index ((b*H+h)*N+q)*N+k. */
+int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate,
+                      uint32_t drop_key, void* stream);
+int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N,
+                      int H, int hd, float drop_rate, uint32_t drop_key, void* stream);
+
+/* ---------------------------------------------------------------- glue around the block */
+/* x[b,0,:] = dropout(cls + pos[0]) (ConcatEmbedding + LearnedEmbedding1D + Dropout,
+ * layers/embedding.py:179-180,251-261; vision_transformer.py:249-261). x fp32 [B,N,D]. */
+int chb_cls_row(float* x, const float* cls, const float* pos, int B, int N, int D, float drop_rate, uint32_t drop_key,
+                void* stream);
+/* backward of embedding stage: dx fp32 [B,N,D] -> dpatch bf16 [B*(N-1), D] (masked), dpos fp32
+ * [N,D] and dcls fp32 [D] (accumulated, caller zeroes). */
+int chb_embed_bwd(const float* dx, void* dpatch_bf16, float* dpos, float* dcls, int B, int N, int D, float drop_rate,
+                  uint32_t drop_key, void* stream);
+/* dz = dy * keep * 1/(1-rate) as bf16 (backward of keras Dropout ahead of a GEMM). */
+int chb_dropout_bwd_bf16(const float* dy, int64_t ld, void* dz_bf16, int M, int N, float drop_rate, uint32_t drop_key,
+                         void* stream);
+/* out[N] += column sums of bf16 x[M,ld] (bias gradients). */
+int chb_colsum_bf16(const void* x, int64_t ld, float* out, int M, int N, void* stream);
+/* sparse softmax cross-entropy from logits (mean over batch) + gradient:
+ * loss_per_sample fp32 [B]; dlogits bf16 [B,ld_d] = (softmax - onehot) * grad_scale, pad cols 0. */
+int chb_softmax_ce(const float* logits, int64_t ld, const int32_t* labels, float* loss_per_sample, void* dlogits_bf16,
+                   int64_t ld_d, int B, int classes, float grad_scale, void* stream);
+/* gather/scatter of the pooled cls rows: out bf16 [B,D] <- x bf16 rows b*N ; and
+ * dx fp32 [B*N... ] handled by chb_layernorm_* strides. */
+
+/* fp32 [R,C] -> bf16 [R,C] and/or bf16 [C,R] for a table of matrices (one launch). desc is a
+ * device int64 array [n,4] = {src_offset, dst_offset, R, C} in elements; dst_t gets the
+ * transposed copy at dst_offset (same element offsets). Either dst may be NULL. */
+int chb_cast_transpose(const float* src, void* dst_bf16, void* dst_t_bf16, const int64_t* desc, int n_desc,
+                       int max_tiles, void* stream);
+
+/* AdamW (optimizers.py:147-155,372-464 + keras Adam): per element, if decay flag of its
+ * 1024-element chunk is set: p -= wd*p; then m += (g-m)(1-b1); v += (g*g-v)(1-b2);
+ * p -= lr_t*m/(sqrt(v)+eps).  grad_scale multiplies g first (1/world for data parallel). */
+int chb_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay_flags, int64_t n, float lr_t,
+              float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHAMBERS_HIP_H */

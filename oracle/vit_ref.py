@@ -1,0 +1,222 @@
+"""CPU oracle for the chambers ViT hot path (TEST INFRASTRUCTURE ONLY — see
+oracle/augment_ref.py header for who may import this).
+
+torch-CPU fp32 restatement, written from the reference text, of
+  models/backbones/vision_transformer.py:172-292  (model graph, cls pooling, heads)
+  layers/transformer.py:8-77,256-314              (pre-norm EncoderLayer, Encoder)
+  layers/attention.py:7-127                       (MultiHeadAttention, ScaledAttention)
+  layers/embedding.py:156-182,218-261             (LearnedEmbedding1D, ConcatEmbedding)
+  activations.py:46-56                            (exact-erf GELU)
+  optimizers.py:147-181,372-464                   (AdamW: decay first, then Adam)
+
+PARITY STATUS: **parity unpinned.**  The reference's only numerical statement for
+this path is the manual script test_units/manual_test_vit_weights.py:245-341
+(chambers ViT == timm ViT under the weight mapping, atol 1e-5..1e-3), which needs
+tensorflow, timm and network access; none can run here.  The arithmetic itself
+lives in keras/tensorflow 2.6.0 (LayerNormalization, Dense, Conv2D, Attention,
+Dropout, Adam) whose published algorithms are restated below.  `timm_block`
+restates the timm block the manual script compares against, and
+tests/test_oracle_vit.py checks this oracle equals it under the script's weight
+mapping (:27-76), which is the one equivalence the reference does state.
+
+Gradients come from torch autograd over this forward.  Dropout masks are explicit
+(oracle/rng_ref.py defines them).  ``emulate_bf16=True`` rounds every GEMM operand
+to bfloat16 (fp32 accumulate), mirroring the build's compute mode, so that tests
+can separate precision noise from real defects; the fp32 path is the reference
+semantics.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import rng_ref
+
+
+# --------------------------------------------------------------------------- #
+# configuration / dropout-site numbering (shared convention with chambers_amd.engine)
+# --------------------------------------------------------------------------- #
+SITE_EMBED = 0          # Dropout after pos_embedding (vision_transformer.py:261)
+
+
+def site_attn(layer):   # dropout on attention probabilities (layers/attention.py:44-46)
+    return 1 + 3 * layer
+
+
+def site_proj(layer):   # dropout1 (layers/transformer.py:38,69)
+    return 2 + 3 * layer
+
+
+def site_mlp(layer):    # dropout2 (layers/transformer.py:48,76)
+    return 3 + 3 * layer
+
+
+def _bf(x, on):
+    return x.to(torch.bfloat16).to(torch.float32) if on else x
+
+
+def _drop(x, rate, key):
+    """tf.nn.dropout: x * 1/(1-rate) * keep (keras Dropout, training)."""
+    if rate == 0.0 or key is None:
+        return x
+    keep = rng_ref.keep_mask(x.numel(), key, rate).reshape(tuple(x.shape))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+    return x * float(scale) * torch.from_numpy(keep).to(x.dtype)
+
+
+def gelu(x):
+    """activations.py:46-56 (exact erf branch)."""
+    return 0.5 * x * (1.0 + torch.erf(x / 1.4142135623730951))
+
+
+def layer_norm(x, gamma, beta, eps):
+    """keras LayerNormalization (upstream restated): biased variance over the
+    last axis, gamma * (x - mean) * rsqrt(var + eps) + beta."""
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+def multi_head_attention(x, p, prefix, num_heads, rate, key, bf16):
+    """layers/attention.py:99-127 with q = v = k = x (layers/transformer.py:66-68)."""
+    wq, bq = p[prefix + "w_query"], p[prefix + "b_query"]
+    wv, bv = p[prefix + "w_value"], p[prefix + "b_value"]
+    wk, bk = p[prefix + "w_key"], p[prefix + "b_key"]
+    wp, bp = p[prefix + "w_projection"], p[prefix + "b_projection"]
+    head_dim = wq.shape[-1]
+    xb = _bf(x, bf16)
+    query = torch.einsum("btd,dnh->bnth", xb, _bf(wq, bf16)) + bq
+    value = torch.einsum("btd,dnh->bnth", xb, _bf(wv, bf16)) + bv
+    keyt = torch.einsum("btd,dnh->bnth", xb, _bf(wk, bf16)) + bk
+    query, value, keyt = _bf(query, bf16), _bf(value, bf16), _bf(keyt, bf16)
+    # ScaledAttention._calculate_scores (layers/attention.py:13-23): matmul, THEN divide
+    scores = torch.matmul(query, keyt.transpose(-1, -2)) / math.sqrt(head_dim)
+    weights = torch.softmax(scores, dim=-1)
+    weights = _drop(weights, rate, key)
+    attn = torch.matmul(_bf(weights, bf16), value)
+    attn = _bf(attn, bf16)
+    return torch.einsum("bnth,ndh->btd", attn, _bf(wp, bf16)) + bp
+
+
+def encoder_layer(x, p, prefix, cfg, keys, layer, bf16):
+    """EncoderLayer.call pre-norm branch, layers/transformer.py:56-58,65-77."""
+    rate = cfg["dropout_rate"]
+    eps = cfg.get("norm_epsilon", 1e-6)
+    h = layer_norm(x, p[prefix + "norm1/gamma"], p[prefix + "norm1/beta"], eps)
+    a = multi_head_attention(h, p, prefix + "multi_head_attention/", cfg["n_heads"], rate,
+                             keys.get(site_attn(layer)), bf16)
+    x = x + _drop(a, rate, keys.get(site_proj(layer)))
+    h = layer_norm(x, p[prefix + "norm2/gamma"], p[prefix + "norm2/beta"], eps)
+    u = gelu(torch.matmul(_bf(h, bf16), _bf(p[prefix + "dense1/kernel"], bf16)) + p[prefix + "dense1/bias"])
+    y = torch.matmul(_bf(u, bf16), _bf(p[prefix + "dense2/kernel"], bf16)) + p[prefix + "dense2/bias"]
+    return x + _drop(y, rate, keys.get(site_mlp(layer)))
+
+
+def patch_embed(images, kernel, bias, patch, bf16):
+    """Conv2D(D, kernel=p, stride=p, 'valid') + Reshape([-1, D])
+    (vision_transformer.py:235-248); kernel is HWIO [p, p, C, D]."""
+    b, h, w, c = images.shape
+    gh, gw = h // patch, w // patch
+    x = images[:, :gh * patch, :gw * patch, :].reshape(b, gh, patch, gw, patch, c)
+    x = x.permute(0, 1, 3, 2, 4, 5).reshape(b, gh * gw, patch * patch * c)
+    k2 = kernel.reshape(patch * patch * c, -1)
+    return torch.matmul(_bf(x, bf16), _bf(k2, bf16)) + bias
+
+
+def vit_forward(p, images, cfg, keys=None, bf16=False, return_tokens=False):
+    """VisionTransformer graph, vision_transformer.py:235-283.
+    ``images``: float32 NHWC, already normalised.  ``keys``: {site: key} for
+    training-mode dropout, None/{} for inference.  Returns logits (or the
+    pooled/feature vector when the model has no top)."""
+    keys = keys or {}
+    rate = cfg["dropout_rate"]
+    x = patch_embed(images, p["patch_embeddings/embedding/kernel"],
+                    p["patch_embeddings/embedding/bias"], cfg["patch_size"], bf16)
+    b = x.shape[0]
+    cls = p["add_cls_token/embeddings"].unsqueeze(0).expand(b, -1, -1)
+    x = torch.cat([cls, x], dim=1)                       # ConcatEmbedding side="left"
+    x = x + p["pos_embedding/embeddings"]                # LearnedEmbedding1D
+    x = _drop(x, rate, keys.get(SITE_EMBED))
+    for i in range(cfg["n_encoder_layers"]):
+        x = encoder_layer(x, p, "encoder/layer_%d/" % i, cfg, keys, i, bf16)
+    x = layer_norm(x, p["encoder/norm/gamma"], p["encoder/norm/beta"],
+                   cfg.get("norm_epsilon", 1e-6))
+    if return_tokens:
+        return x
+    pooling = cfg.get("pooling", "cls")
+    if pooling == "cls":
+        x = x[:, 0, :]
+    elif pooling == "avg":
+        x = x[:, 1:, :].mean(dim=1)
+    elif pooling == "max":
+        x = x[:, 1:, :].max(dim=1).values
+    elif pooling == "sum":
+        x = x[:, 1:, :].sum(dim=1)
+    if "feature/kernel" in p:
+        x = torch.tanh(torch.matmul(_bf(x, bf16), _bf(p["feature/kernel"], bf16)) + p["feature/bias"])
+    if "predictions/kernel" in p:
+        x = torch.matmul(_bf(x, bf16), _bf(p["predictions/kernel"], bf16)) + p["predictions/bias"]
+    return x
+
+
+def sparse_ce_from_logits(logits, labels):
+    """keras SparseCategoricalCrossentropy(from_logits=True), mean over the batch."""
+    return torch.nn.functional.cross_entropy(logits, labels, reduction="mean")
+
+
+def adamw_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7,
+               weight_decay=0.0, decay_mask=None):
+    """optimizers.py:147-155 then keras Adam (upstream restated):
+    var -= wd*var (wd NOT scaled by lr); m,v update; var -= lr_t*m/(sqrt(v)+eps),
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t).  In place on fp32 numpy-backed tensors."""
+    # keras Adam keeps its hyper-parameters as float32 tensors: 1-beta, beta^t and lr_t are fp32 expressions
+    b1, b2 = np.float32(beta1), np.float32(beta2)
+    lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - np.power(b2, np.float32(step))) / (np.float32(1.0) - np.power(b1, np.float32(step)))
+    for name in params:
+        w, g = params[name], grads[name]
+        if decay_mask is None or decay_mask.get(name, True):
+            w.sub_(np.float32(weight_decay) * w)
+        m[name].add_((g - m[name]) * float(np.float32(1.0) - b1))
+        v[name].add_((g * g - v[name]) * float(np.float32(1.0) - b2))
+        w.sub_(float(lr_t) * m[name] / (torch.sqrt(v[name]) + np.float32(eps)))
+
+
+# --------------------------------------------------------------------------- #
+# timm block, for the one equivalence the reference states
+# --------------------------------------------------------------------------- #
+def timm_block(x, w, num_heads, eps=1e-6):
+    """timm VisionTransformer Block forward (what manual_test_vit_weights.py:252-279
+    compares chambers' EncoderLayer against).  ``w`` holds timm-named tensors."""
+    b, n, d = x.shape
+    hd = d // num_heads
+    h = torch.nn.functional.layer_norm(x, (d,), w["norm1.weight"], w["norm1.bias"], eps)
+    qkv = torch.nn.functional.linear(h, w["attn.qkv.weight"], w["attn.qkv.bias"])
+    qkv = qkv.reshape(b, n, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+    attn = attn.softmax(dim=-1)
+    o = (attn @ v).transpose(1, 2).reshape(b, n, d)
+    x = x + torch.nn.functional.linear(o, w["attn.proj.weight"], w["attn.proj.bias"])
+    h = torch.nn.functional.layer_norm(x, (d,), w["norm2.weight"], w["norm2.bias"], eps)
+    u = torch.nn.functional.gelu(torch.nn.functional.linear(h, w["mlp.fc1.weight"], w["mlp.fc1.bias"]))
+    return x + torch.nn.functional.linear(u, w["mlp.fc2.weight"], w["mlp.fc2.bias"])
+
+
+def timm_to_chambers_block(w, num_heads):
+    """map_encoder_layer, test_units/manual_test_vit_weights.py:27-76."""
+    dim = w["attn.proj.weight"].shape[0]
+    hd = dim // num_heads
+    wq, wk, wv = w["attn.qkv.weight"].reshape(3, num_heads, hd, dim).permute(0, 3, 1, 2)
+    bq, bk, bv = w["attn.qkv.bias"].reshape(3, num_heads, 1, hd)
+    wp = w["attn.proj.weight"].reshape(dim, num_heads, hd).permute(1, 0, 2)
+    return {
+        "multi_head_attention/w_query": wq.contiguous(), "multi_head_attention/b_query": bq.contiguous(),
+        "multi_head_attention/w_value": wv.contiguous(), "multi_head_attention/b_value": bv.contiguous(),
+        "multi_head_attention/w_key": wk.contiguous(), "multi_head_attention/b_key": bk.contiguous(),
+        "multi_head_attention/w_projection": wp.contiguous(),
+        "multi_head_attention/b_projection": w["attn.proj.bias"].unsqueeze(0),
+        "norm1/gamma": w["norm1.weight"], "norm1/beta": w["norm1.bias"],
+        "dense1/kernel": w["mlp.fc1.weight"].t().contiguous(), "dense1/bias": w["mlp.fc1.bias"],
+        "dense2/kernel": w["mlp.fc2.weight"].t().contiguous(), "dense2/bias": w["mlp.fc2.bias"],
+        "norm2/gamma": w["norm2.weight"], "norm2/beta": w["norm2.bias"],
+    }

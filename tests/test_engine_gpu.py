@@ -1,0 +1,159 @@
+"""GPU parity of the whole hot path (uint8 batch -> RandAugment -> normalise -> ViT forward -> loss ->
+backward -> AdamW) against the CPU oracle on the same seeded inputs, decisions and dropout keys.
+
+Tolerances: the oracle is evaluated twice — in plain fp32 (the reference semantics) and with the build's
+operand rounding emulated (bf16 GEMM inputs, fp32 accumulate).  Against the emulating oracle the logits
+must agree to rel-L2 2e-3 (inference) and gradients to 3e-2 (their intermediates are stored in bf16);
+against the plain fp32 oracle the bound is 2e-2 (logits), documenting the bf16-vs-fp32 gap itself.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_ref as A
+from oracle import rng_ref, vit_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _cfg(**kw):
+    from chambers_amd.engine import ViTConfig
+    base = dict(patch_size=16, patch_dim=128, n_encoder_layers=2, n_heads=2, ff_dim=256, dropout_rate=0.1, image_size=(64, 48), classes=10)
+    base.update(kw)
+    return ViTConfig(**base)
+
+
+def _setup(cfg, bsz, training, seed=3):
+    from chambers_amd.engine import ViTEngine, init_keras_weights
+    kw = init_keras_weights(cfg, seed=1234)
+    g = np.random.Generator(np.random.PCG64(0))
+    # non-trivial biases / LN params so every term is exercised
+    for k in kw:
+        if k.endswith(("bias", "beta", "b_query", "b_key", "b_value", "b_projection")):
+            kw[k] = (g.normal(0, 0.05, size=kw[k].shape)).astype(np.float32)
+        if k.endswith("gamma"):
+            kw[k] = (1.0 + g.normal(0, 0.1, size=kw[k].shape)).astype(np.float32)
+    eng = ViTEngine(cfg, bsz, training=training, seed=seed)
+    eng.load_keras_weights(kw)
+    images = g.integers(0, 256, size=(bsz,) + cfg.image_size + (3,), dtype=np.uint8)
+    labels = g.integers(0, cfg.classes, size=(bsz,))
+    return eng, kw, images, labels
+
+
+def _oracle_params(kw, requires_grad=False):
+    return {k: torch.tensor(v, dtype=torch.float32, requires_grad=requires_grad) for k, v in kw.items()}
+
+
+def _keys(cfg, seed, step):
+    n_sites = 1 + 3 * cfg.n_encoder_layers
+    return {s: rng_ref.site_key(seed, step, s) for s in range(n_sites)}
+
+
+def test_keras_internal_weight_roundtrip():
+    from chambers_amd.engine import init_keras_weights, internal_to_keras, keras_to_internal
+    cfg = _cfg()
+    kw = init_keras_weights(cfg)
+    back = internal_to_keras(keras_to_internal(kw, cfg), cfg)
+    assert set(back) == set(kw)
+    for k in kw:
+        np.testing.assert_array_equal(back[k], kw[k])
+
+
+@pytest.mark.parametrize("bsz", [4, 3])
+def test_forward_inference_matches_oracle(bsz):
+    cfg = _cfg()
+    eng, kw, images, _ = _setup(cfg, bsz, training=False)
+    logits = eng.forward(torch.as_tensor(images, device="cuda"), training=False).cpu()
+    x = torch.from_numpy(A.imagenet_normalize(images, "tf"))
+    p = _oracle_params(kw)
+    ref_bf = vit_ref.vit_forward(p, x, cfg.as_oracle_cfg(), keys=None, bf16=True)
+    ref_32 = vit_ref.vit_forward(p, x, cfg.as_oracle_cfg(), keys=None, bf16=False)
+    assert rel_l2(logits, ref_bf) < 2e-3, rel_l2(logits, ref_bf)
+    assert rel_l2(logits, ref_32) < 2e-2, rel_l2(logits, ref_32)
+    exported = eng.export_keras_weights()
+    for k in kw:
+        np.testing.assert_array_equal(exported[k], kw[k])
+
+
+def test_train_step_matches_oracle():
+    cfg = _cfg()
+    bsz, seed = 4, 3
+    eng, kw, images, labels = _setup(cfg, bsz, training=True, seed=seed)
+    lab = torch.as_tensor(labels)
+    logits = eng.forward(torch.as_tensor(images, device="cuda"), training=True)
+    loss = eng.loss(lab.cuda()).cpu()
+    eng.backward()
+    grads = eng.export_keras_grads()
+
+    x = torch.from_numpy(A.imagenet_normalize(images, "tf"))
+    p = _oracle_params(kw, requires_grad=True)
+    keys = _keys(cfg, seed, 0)
+    ref_logits = vit_ref.vit_forward(p, x, cfg.as_oracle_cfg(), keys=keys, bf16=True)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, lab, reduction="none")
+    ref_loss.mean().backward()
+    assert rel_l2(logits.cpu(), ref_logits.detach()) < 3e-3, rel_l2(logits.cpu(), ref_logits.detach())
+    assert rel_l2(loss, ref_loss.detach()) < 3e-3
+    worst = {}
+    for k in kw:
+        r = rel_l2(grads[k], p[k].grad)
+        worst[k] = r
+        assert r < 3e-2, "grad %s rel-l2 %g" % (k, r)
+    # optimizer: one AdamW step on the oracle's weights with the ENGINE's gradients isolates the update rule
+    gk = {k: torch.tensor(v) for k, v in grads.items()}
+    pw = {k: torch.tensor(v) for k, v in kw.items()}
+    m = {k: torch.zeros_like(v) for k, v in pw.items()}
+    v_ = {k: torch.zeros_like(v) for k, v in pw.items()}
+    vit_ref.adamw_step(pw, gk, m, v_, 1, lr=1e-3, weight_decay=0.01)
+    eng.adamw_step(learning_rate=1e-3, weight_decay=0.01)
+    new = eng.export_keras_weights()
+    for k in kw:
+        assert np.allclose(new[k], pw[k].numpy(), rtol=1e-5, atol=2e-7), k
+    # operand images were refreshed from the new master weights
+    w = eng.p("encoder/layer_0/dense1/kernel")
+    assert torch.equal(eng.wb("encoder/layer_0/dense1/kernel"), w.to(torch.bfloat16))
+    assert torch.equal(eng.wbt("encoder/layer_0/dense1/kernel"), w.to(torch.bfloat16).t().contiguous())
+
+
+def test_second_step_uses_new_dropout_keys_and_runs():
+    cfg = _cfg()
+    eng, kw, images, labels = _setup(cfg, 4, training=True)
+    img = torch.as_tensor(images, device="cuda")
+    lab = torch.as_tensor(labels, device="cuda")
+    l0 = eng.train_step(img, lab, learning_rate=1e-3).clone()
+    l1 = eng.train_step(img, lab, learning_rate=1e-3).clone()
+    assert torch.isfinite(l0).all() and torch.isfinite(l1).all()
+    assert eng.opt_step == 2
+    for _ in range(20):
+        l = eng.train_step(img, lab, learning_rate=1e-3)
+    assert float(l.mean()) < float(l0.mean())     # memorises 4 samples
+
+
+def test_full_pipeline_with_randaugment_matches_oracle():
+    from chambers_amd import augmentations as aug
+    cfg = _cfg()
+    bsz = 4
+    eng, kw, images, _ = _setup(cfg, bsz, training=False)
+    g = np.random.Generator(np.random.PCG64(42))
+    dec = [{"op": int(g.integers(0, 16)), "negate": bool(g.uniform() < 0.5),
+            "centers": np.stack([g.integers(0, 64, size=bsz), g.integers(0, 48, size=bsz)], axis=1).astype(np.int32)} for _ in range(2)]
+    xa = aug.RandAugment(2, 9)(torch.as_tensor(images, device="cuda"), training=True, decisions=dec)
+    ref_aug = A.rand_augment(images, 2, 9, dec)
+    np.testing.assert_array_equal(xa.cpu().numpy(), ref_aug)
+    logits = eng.forward(xa, training=False).cpu()
+    ref = vit_ref.vit_forward(_oracle_params(kw), torch.from_numpy(A.imagenet_normalize(ref_aug, "tf")), cfg.as_oracle_cfg(), bf16=True)
+    assert rel_l2(logits, ref) < 2e-3
+
+
+def test_vit_tiny_224_forward_config1():
+    """BASELINE config 1: ViT-Ti/16 forward on 8x224x224x3 (the reference's CPU-runnable case)."""
+    cfg = _cfg(patch_dim=192, n_heads=3, ff_dim=768, n_encoder_layers=12, image_size=(224, 224), classes=1000, dropout_rate=0.1)
+    eng, kw, images, _ = _setup(cfg, 8, training=False)
+    logits = eng.forward(torch.as_tensor(images, device="cuda"), training=False).cpu()
+    ref = vit_ref.vit_forward(_oracle_params(kw), torch.from_numpy(A.imagenet_normalize(images, "tf")), cfg.as_oracle_cfg(), bf16=True)
+    assert tuple(logits.shape) == (8, 1000)
+    assert rel_l2(logits, ref) < 5e-3, rel_l2(logits, ref)

@@ -1,0 +1,361 @@
+"""GPU parity of the ViT-block kernels, called through the C ABI (chambers_amd.kernels), against
+torch-CPU fp32/fp64 restatements on the same (bf16-rounded) inputs.
+
+Tolerances (north star: 1e-3 relative for bf16 attention / FFN):
+  * kernels with an fp32 output are held to rel-L2 <= 1e-3 against the fp64 result computed from the
+    SAME bf16 operands (in practice ~1e-6: fp32 accumulation) ;
+  * the bf16-output variant must equal the fp32-output variant rounded once to bf16 (bit-exact), so
+    its only extra error is the final storage rounding (<= 2^-9 relative per element);
+  * attention rounds the probabilities to bf16 before P.V: rel-L2 <= 1e-3 on the fp32 oracle result
+    is asserted on bf16 outputs against a bf16-rounded oracle with atol = 1 bf16 ulp of max|ref|.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rng_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------ RNG
+def test_dropout_mask_matches_rng_ref():
+    from chambers_amd import kernels as K, rng
+    for n, rate, key in ((1, 0.1, 7), (1001, 0.1, 0xDEADBEEF), (4096, 0.5, 123), (65537, 0.25, 0xFFFFFFFF)):
+        got = K.dropout_mask(n, rate, key).cpu().numpy().astype(bool)
+        np.testing.assert_array_equal(got, rng_ref.keep_mask(n, key, rate))
+    assert rng.site_key(5, 3, 11) == rng_ref.site_key(5, 3, 11)
+    big = K.dropout_mask(1 << 24, 0.1, 99).float().mean().item()
+    assert abs(big - 0.9) < 1e-3
+
+
+# ------------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 192), (197 * 3, 768, 768), (100, 1000, 128), (1, 4, 64), (513, 132, 320)])
+def test_gemm_nt_plain_and_bias(m, n, k):
+    from chambers_amd import kernels as K
+    a = bf(torch.randn(m, k, generator=g(1)))
+    b = bf(torch.randn(n, k, generator=g(2)))
+    bias = torch.randn(n, generator=g(3))
+    ref = a.double() @ b.double().t() + bias.double()
+    out32 = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    K.gemm_nt(a.cuda(), b.cuda(), out32, bias=bias.cuda())
+    assert rel_l2(out32.cpu(), ref) < 1e-3
+    assert rel_l2(out32.cpu(), ref) < 2e-6
+    out16 = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    K.gemm_nt(a.cuda(), b.cuda(), out16, bias=bias.cuda())
+    assert torch.equal(out16, out32.to(torch.bfloat16))
+    # A = I with an ASYMMETRIC B catches a transposed C write
+    if m == k:
+        eye = bf(torch.eye(m))
+        o = torch.empty(m, n, dtype=torch.float32, device="cuda")
+        K.gemm_nt(eye.cuda(), b.cuda(), o)
+        assert torch.equal(o.cpu(), b.float().t().contiguous())
+
+
+def test_gemm_nt_padded_rows_untouched_and_strides():
+    from chambers_amd import kernels as K
+    m, n, k = 197, 192, 128
+    a = bf(torch.randn(256, k, generator=g(4))).cuda()
+    b = bf(torch.randn(n, k, generator=g(5))).cuda()
+    out = torch.full((256, n), 7.0, dtype=torch.float32, device="cuda")
+    K.gemm_nt(a, b, out, m=m)
+    assert torch.all(out[m:] == 7.0)
+    ref = a[:m].double().cpu() @ b.double().cpu().t()
+    assert rel_l2(out[:m].cpu(), ref) < 2e-6
+
+
+def test_gemm_nt_gelu_and_dgelu():
+    from chambers_amd import kernels as K
+    m, n, k = 300, 256, 128
+    a = bf(torch.randn(m, k, generator=g(6)))
+    b = bf(torch.randn(n, k, generator=g(7)) * 0.2)
+    bias = torch.randn(n, generator=g(8)) * 0.1
+    pre = a.double() @ b.double().t() + bias.double()
+    ref = 0.5 * pre * (1 + torch.erf(pre / math.sqrt(2.0)))
+    out = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    aux = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    K.gemm_nt(a.cuda(), b.cuda(), out, bias=bias.cuda(), epilogue=K.EPI_GELU, aux=aux)
+    assert rel_l2(out.cpu(), ref) < 1e-5
+    assert rel_l2(aux.float().cpu(), pre) < 3e-3 and torch.equal(aux.cpu(), bf(pre.float()))
+    # backward epilogue: C = acc * gelu'(aux)
+    dy = bf(torch.randn(m, k, generator=g(9)))
+    acc = dy.double() @ b.double().t()
+    x = aux.double().cpu()
+    dg = 0.5 * (1 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    out2 = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    K.gemm_nt(dy.cuda(), b.cuda(), out2, epilogue=K.EPI_DGELU, aux=aux)
+    assert rel_l2(out2.cpu(), acc * dg) < 1e-5
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.1])
+def test_gemm_nt_residual_dropout(rate):
+    from chambers_amd import kernels as K
+    m, n, k = 197 * 2, 192, 192
+    a = bf(torch.randn(m, k, generator=g(10)))
+    b = bf(torch.randn(n, k, generator=g(11)) * 0.1)
+    bias = torch.randn(n, generator=g(12))
+    resid = torch.randn(m, n, generator=g(13))
+    key = 0xABCDEF
+    y = a.double() @ b.double().t() + bias.double()
+    if rate:
+        keep = torch.from_numpy(rng_ref.keep_mask(m * n, key, rate).reshape(m, n))
+        y = y * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * keep
+    ref = resid.double() + y
+    out = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    K.gemm_nt(a.cuda(), b.cuda(), out, bias=bias.cuda(), epilogue=K.EPI_RESID, resid=resid.cuda(), drop_rate=rate, drop_key=key)
+    assert rel_l2(out.cpu(), ref) < 2e-6
+    # in place on the residual buffer
+    r2 = resid.cuda().clone()
+    K.gemm_nt(a.cuda(), b.cuda(), r2, bias=bias.cuda(), epilogue=K.EPI_RESID, resid=r2, drop_rate=rate, drop_key=key)
+    assert torch.equal(r2, out)
+
+
+def test_gemm_nt_patch_epilogue_and_cls_row():
+    from chambers_amd import kernels as K
+    bsz, npatch, k, d = 3, 12, 192, 128
+    a = bf(torch.randn(bsz * npatch, k, generator=g(14)))
+    w = bf(torch.randn(d, k, generator=g(15)) * 0.1)
+    bias = torch.randn(d, generator=g(16))
+    pos = torch.randn(npatch + 1, d, generator=g(17))
+    cls = torch.randn(d, generator=g(18))
+    rate, key = 0.1, 4242
+    x = torch.zeros(bsz * (npatch + 1), d, dtype=torch.float32, device="cuda")
+    K.gemm_nt(a.cuda(), w.cuda(), x, bias=bias.cuda(), epilogue=K.EPI_PATCH, resid=pos.cuda(), period=npatch, drop_rate=rate, drop_key=key)
+    K.cls_row(x, cls.cuda(), pos.cuda(), bsz, npatch + 1, d, rate, key)
+    tok = (a.double() @ w.double().t() + bias.double()).reshape(bsz, npatch, d)
+    full = torch.cat([cls.double().expand(bsz, 1, d), tok], dim=1) + pos.double()
+    keep = torch.from_numpy(rng_ref.keep_mask(full.numel(), key, rate).reshape(full.shape))
+    ref = full * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * keep
+    assert rel_l2(x.cpu().reshape(bsz, npatch + 1, d), ref) < 2e-6
+
+
+def test_gemm_nt_rejects_bad_shapes():
+    from chambers_amd import kernels as K
+    a = torch.zeros(8, 48, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros(8, 48, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        K.gemm_nt(a, b, torch.empty(8, 8, dtype=torch.float32, device="cuda"))      # K % 64
+    with pytest.raises(ValueError):
+        K.gemm_nt(a.float(), b, torch.empty(8, 8, dtype=torch.float32, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------ GEMM TN
+@pytest.mark.parametrize("m,kd,nd", [(64, 128, 128), (256, 192, 576), (1024, 768, 256), (197 * 64, 192, 768), (128, 200, 72)])
+def test_gemm_tn(m, kd, nd):
+    from chambers_amd import kernels as K
+    x = bf(torch.randn(m, kd, generator=g(20)))
+    dy = bf(torch.randn(m, nd, generator=g(21)))
+    ref = x.double().t() @ dy.double()
+    dw = torch.zeros(kd, nd, dtype=torch.float32, device="cuda")
+    K.gemm_tn(x.cuda(), dy.cuda(), dw)
+    assert rel_l2(dw.cpu(), ref) < 5e-6
+    K.gemm_tn(x.cuda(), dy.cuda(), dw)           # accumulates
+    assert rel_l2(dw.cpu(), 2 * ref) < 5e-6
+    # asymmetric identity check: X = [I; 0] -> dW = dY[:kd]
+    if m >= kd and kd % 64 == 0:
+        xi = torch.zeros(m, kd)
+        xi[:kd] = torch.eye(kd)
+        o = torch.zeros(kd, nd, dtype=torch.float32, device="cuda")
+        K.gemm_tn(bf(xi).cuda(), dy.cuda(), o)
+        assert torch.equal(o.cpu(), dy[:kd].float())
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("m,d", [(7, 192), (197 * 2, 768), (33, 1024), (5, 384), (1, 64)])
+def test_layernorm_fwd_bwd(m, d):
+    from chambers_amd import kernels as K
+    x = torch.randn(m, d, generator=g(30)) * 2 + 0.5
+    gamma = torch.randn(d, generator=g(31))
+    beta = torch.randn(d, generator=g(32))
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (d,), gd, bd, 1e-6)
+    y = torch.empty(m, d, dtype=torch.bfloat16, device="cuda")
+    mean = torch.empty(m, dtype=torch.float32, device="cuda")
+    rstd = torch.empty(m, dtype=torch.float32, device="cuda")
+    K.layernorm_fwd(x.cuda(), d, gamma.cuda(), beta.cuda(), y, mean, rstd, m, d, 1e-6)
+    assert torch.equal(y.cpu(), bf(ref.detach().float())) or rel_l2(y.float().cpu(), ref.detach()) < 3e-3
+    assert rel_l2(mean.cpu(), x.double().mean(-1)) < 1e-5
+    dy = bf(torch.randn(m, d, generator=g(33)))
+    ref.backward(dy.double())
+    dx0 = torch.randn(m, d, generator=g(34))
+    dx = dx0.cuda().clone()
+    dg = torch.zeros(d, dtype=torch.float32, device="cuda")
+    db = torch.zeros(d, dtype=torch.float32, device="cuda")
+    K.layernorm_bwd(dy.cuda(), x.cuda(), d, mean, rstd, gamma.cuda(), dx, d, True, dg, db, m, d)
+    assert rel_l2(dx.cpu(), dx0.double() + xd.grad) < 1e-5
+    assert rel_l2(dg.cpu(), gd.grad) < 1e-5 and rel_l2(db.cpu(), bd.grad) < 1e-5
+    dx2 = torch.full((m, d), 9.0, dtype=torch.float32, device="cuda")
+    K.layernorm_bwd(dy.cuda(), x.cuda(), d, mean, rstd, gamma.cuda(), dx2, d, False, dg, db, m, d)
+    assert rel_l2(dx2.cpu(), xd.grad) < 1e-5
+
+
+def test_layernorm_strided_rows():
+    from chambers_amd import kernels as K
+    bsz, n, d = 4, 5, 192
+    x = torch.randn(bsz * n, d, generator=g(35)).cuda()
+    gamma, beta = torch.ones(d).cuda(), torch.zeros(d).cuda()
+    y = torch.empty(bsz, d, dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.empty(bsz, device="cuda"), torch.empty(bsz, device="cuda")
+    K.layernorm_fwd(x, n * d, gamma, beta, y, mean, rstd, bsz, d, 1e-6)
+    ref = torch.nn.functional.layer_norm(x[::n].double().cpu(), (d,), None, None, 1e-6)
+    assert rel_l2(y.float().cpu(), ref) < 3e-3
+
+
+# ------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, bsz, n, h, rate, key):
+    """fp64 restatement on the given (bf16-valued) qkv; returns o, lse and autograd handles."""
+    d = h * 64
+    t = qkv.double().reshape(bsz, n, 3, h, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    p = torch.softmax(s, dim=-1)
+    lse = torch.logsumexp(s, dim=-1)
+    if rate:
+        keep = torch.from_numpy(rng_ref.keep_mask(p.numel(), key, rate).reshape(p.shape))
+        p = p * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * keep
+    o = (p @ v).permute(0, 2, 1, 3).reshape(bsz * n, d)
+    return o, lse
+
+
+@pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.0), (2, 197, 3, 0.1), (3, 17, 2, 0.1), (1, 64, 1, 0.0), (2, 33, 4, 0.5),
+                                          (1, 128, 2, 0.1), (1, 577, 2, 0.1), (1, 1, 1, 0.0), (2, 224, 1, 0.1)])
+def test_attention_fwd_bwd(bsz, n, h, rate):
+    from chambers_amd import kernels as K
+    d = h * 64
+    key = 0x1234567
+    qkv = bf(torch.randn(bsz * n, 3 * d, generator=g(40)))
+    qkv_ref = qkv.double().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qkv_ref, bsz, n, h, rate, key)
+    o = torch.empty(bsz * n, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(bsz * h * n, dtype=torch.float32, device="cuda")
+    K.attention_fwd(qkv.cuda(), o, lse, bsz, n, h, 64, rate, key)
+    scale = float(o_ref.detach().abs().max())
+    err = (o.float().cpu().double() - o_ref.detach()).abs().max().item()
+    assert err <= scale * 2 ** -7, "attention fwd max err %g vs scale %g" % (err, scale)
+    assert rel_l2(o.float().cpu(), o_ref.detach()) < 4e-3      # bf16 storage of o + bf16 P: ~2e-3
+    assert rel_l2(lse.cpu().reshape(bsz, h, n), lse_ref.detach()) < 1e-5
+    if n > 224:
+        return  # backward keeps a whole head in LDS: N <= 224
+    do = bf(torch.randn(bsz * n, d, generator=g(41)))
+    o_ref.backward(do.double())
+    dqkv = torch.zeros(bsz * n, 3 * d, dtype=torch.bfloat16, device="cuda")
+    K.attention_bwd(qkv.cuda(), o, do.cuda(), lse, dqkv, bsz, n, h, 64, rate, key)
+    gref = qkv_ref.grad
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        r = rel_l2(dqkv[:, sl].float().cpu(), gref[:, sl])
+        assert r < 1e-2, "%s rel-l2 %g" % (name, r)
+
+
+def test_attention_fwd_fp32_probabilities_tolerance():
+    """The north-star bound (1e-3 rel) on the quantity the kernel computes in fp32: the lse / softmax."""
+    from chambers_amd import kernels as K
+    bsz, n, h = 2, 197, 12
+    qkv = bf(torch.randn(bsz * n, 3 * h * 64, generator=g(42)) * 2)
+    _, lse_ref = _attn_ref(qkv, bsz, n, h, 0.0, 0)
+    o = torch.empty(bsz * n, h * 64, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(bsz * h * n, dtype=torch.float32, device="cuda")
+    K.attention_fwd(qkv.cuda(), o, lse, bsz, n, h, 64)
+    assert rel_l2(lse.cpu().reshape(bsz, h, n), lse_ref) < 1e-3
+    assert torch.allclose(lse.cpu().reshape(bsz, h, n).double(), lse_ref, rtol=1e-3, atol=1e-4)
+
+
+def test_attention_rejects_unsupported():
+    from chambers_amd import kernels as K
+    z = torch.zeros(4, 3 * 32, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        K.attention_fwd(z, z, torch.zeros(4, device="cuda"), 1, 4, 1, 32)   # head_dim != 64
+
+
+# ------------------------------------------------------------------------------------ glue
+def test_colsum_dropout_bwd_embed_bwd():
+    from chambers_amd import kernels as K
+    m, n = 1000, 320
+    x = bf(torch.randn(m, n, generator=g(50)))
+    out = torch.zeros(n, dtype=torch.float32, device="cuda")
+    K.colsum(x.cuda(), out)
+    assert rel_l2(out.cpu(), x.double().sum(0)) < 1e-5
+    dy = torch.randn(m, n, generator=g(51))
+    dz = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    K.dropout_bwd(dy.cuda(), dz, m, n, 0.1, 77)
+    keep = torch.from_numpy(rng_ref.keep_mask(m * n, 77, 0.1).reshape(m, n))
+    ref = bf(dy * float(np.float32(1) / (np.float32(1) - np.float32(0.1))) * keep)
+    assert torch.equal(dz.cpu(), ref)
+    bsz, nt, d = 3, 5, 64
+    dx = torch.randn(bsz, nt, d, generator=g(52))
+    keep = torch.from_numpy(rng_ref.keep_mask(dx.numel(), 5, 0.1).reshape(dx.shape))
+    dzr = dx * float(np.float32(1) / (np.float32(1) - np.float32(0.1))) * keep
+    dpatch = torch.zeros(bsz * (nt - 1), d, dtype=torch.bfloat16, device="cuda")
+    dpos = torch.zeros(nt, d, device="cuda")
+    dcls = torch.zeros(d, device="cuda")
+    K.embed_bwd(dx.cuda().reshape(bsz * nt, d), dpatch, dpos, dcls, bsz, nt, d, 0.1, 5)
+    assert torch.equal(dpatch.cpu(), bf(dzr[:, 1:].reshape(-1, d)))
+    assert rel_l2(dpos.cpu(), dzr.double().sum(0)) < 1e-6 and rel_l2(dcls.cpu(), dzr[:, 0].double().sum(0)) < 1e-6
+
+
+def test_softmax_ce():
+    from chambers_amd import kernels as K
+    bsz, c, ld = 37, 1000, 1024
+    logits = torch.zeros(bsz, ld)
+    logits[:, :c] = torch.randn(bsz, c, generator=g(60)) * 3
+    labels = torch.randint(0, c, (bsz,), generator=g(61))
+    lg = logits[:, :c].double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lg, labels, reduction="none")
+    ref.mean().backward()
+    loss = torch.empty(bsz, device="cuda")
+    dl = torch.full((bsz, ld), 5.0, dtype=torch.bfloat16, device="cuda")
+    K.softmax_ce(logits.cuda(), labels.to(torch.int32).cuda(), loss, dl, c, 1.0 / bsz)
+    assert rel_l2(loss.cpu(), ref.detach()) < 1e-6
+    assert rel_l2(dl[:, :c].float().cpu(), lg.grad) < 4e-3 and float(dl[:, c:].abs().max()) == 0.0
+
+
+def test_cast_transpose_and_adamw():
+    from chambers_amd import kernels as K
+    from oracle import vit_ref
+    shapes = [(100, 36), (64, 64), (7, 300)]
+    offs, tot = [], 0
+    for r, c in shapes:
+        offs.append(tot)
+        tot += (r * c + 1023) // 1024 * 1024
+    src = torch.randn(tot, generator=g(70))
+    desc = torch.tensor([[o, o, r, c] for o, (r, c) in zip(offs, shapes)], dtype=torch.int64)
+    dst = torch.zeros(tot, dtype=torch.bfloat16, device="cuda")
+    dstt = torch.zeros(tot, dtype=torch.bfloat16, device="cuda")
+    K.cast_transpose(src.cuda(), dst, dstt, desc.cuda(), len(shapes), max(((r + 63) // 64) * ((c + 63) // 64) for r, c in shapes))
+    for o, (r, c) in zip(offs, shapes):
+        m = bf(src[o:o + r * c].reshape(r, c))
+        assert torch.equal(dst[o:o + r * c].cpu().reshape(r, c), m)
+        assert torch.equal(dstt[o:o + r * c].cpu().reshape(c, r), m.t().contiguous())
+    # AdamW, 3 steps, decay on the first 1024-chunk only
+    n = 4096
+    p0 = torch.randn(n, generator=g(71))
+    params = {"a": p0[:1024].clone(), "b": p0[1024:].clone()}
+    m_ = {k: torch.zeros_like(v) for k, v in params.items()}
+    v_ = {k: torch.zeros_like(v) for k, v in params.items()}
+    p = p0.cuda().clone()
+    mm, vv = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    flags = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g(72 + step))
+        vit_ref.adamw_step(params, {"a": grad[:1024], "b": grad[1024:]}, m_, v_, step, lr=1e-3, weight_decay=0.05,
+                           decay_mask={"a": True, "b": False})
+        b1, b2 = np.float32(0.9), np.float32(0.999)
+        lr_t = np.float32(1e-3) * np.sqrt(np.float32(1) - np.power(b2, np.float32(step))) / (np.float32(1) - np.power(b1, np.float32(step)))
+        K.adamw(p, grad.cuda(), mm, vv, flags, float(lr_t), 0.9, 0.999, 1e-7, 0.05)
+    ref = torch.cat([params["a"], params["b"]])
+    assert torch.allclose(p.cpu(), ref, rtol=2e-6, atol=1e-7), float((p.cpu() - ref).abs().max())
