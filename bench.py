@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of a ViT-B/16 224^2 TRAINING step on synthetic ImageNet-shaped batches
+(BASELINE.json `metric`; workload = configs[2]: on-GPU RandAugment(n=2, m=9) -> normalise -> forward ->
+softmax-CE -> backward -> AdamW, batch 512 per GPU, bf16 MFMA compute / fp32 master weights).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU, weak scaling (512 images per GPU), one logical gradient all-reduce per step over RCCL
+(bucketed, overlapped with backward).  Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel
+(the bf16 MFMA GEMM), measured live with HIP events on the launch stream inside the timed region;
+`cpu_baseline` is the CPU oracle (oracle/, kind "port") timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+
+MODELS = {
+    "vitti16": dict(patch_size=16, patch_dim=192, n_encoder_layers=12, n_heads=3, ff_dim=768),
+    "vits16": dict(patch_size=16, patch_dim=384, n_encoder_layers=12, n_heads=6, ff_dim=1536),
+    "vitb16": dict(patch_size=16, patch_dim=768, n_encoder_layers=12, n_heads=12, ff_dim=3072),
+    "vitl16": dict(patch_size=16, patch_dim=1024, n_encoder_layers=24, n_heads=16, ff_dim=4096),
+}
+
+
+def forward_flops_per_image(cfg):
+    """2*n*(3p^2)*D + L*(8*N*D^2 + 4*N^2*D + 4*N*D*ff) + 2*D*classes."""
+    n, N, D, L, ff = cfg.n_patches, cfg.n_tokens, cfg.patch_dim, cfg.n_encoder_layers, cfg.ff_dim
+    return 2 * n * cfg.patch_k * D + L * (8 * N * D * D + 4 * N * N * D + 4 * N * D * ff) + 2 * D * cfg.classes
+
+
+class KernelTimer:
+    """HIP-event bracket around selected launches (events are recorded on the stream the kernels run on)."""
+
+    def __init__(self):
+        self.records = []   # (name, work, start_event, stop_event)
+        self.enabled = False
+
+    def wrap(self, K):
+        timer = self
+        orig_nt, orig_tn = K.gemm_nt, K.gemm_tn
+
+        def gemm_nt(a, b, out, m=None, **kw):
+            if not timer.enabled:
+                return orig_nt(a, b, out, m=m, **kw)
+            mm = a.shape[0] if m is None else m
+            name = "gemm_nt_kernel<%d, %d>" % (kw.get("epilogue", 0), 1 if out.dtype == torch.float32 else 0)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_nt(a, b, out, m=m, **kw)
+            e.record()
+            timer.records.append((name, 2.0 * mm * b.shape[0] * b.shape[1], s, e))
+            return r
+
+        def gemm_tn(x, dy, dw, m=None):
+            if not timer.enabled:
+                return orig_tn(x, dy, dw, m=m)
+            mm = x.shape[0] if m is None else m
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_tn(x, dy, dw, m=m)
+            e.record()
+            timer.records.append(("gemm_tn_kernel", 2.0 * mm * x.shape[1] * dy.shape[1], s, e))
+            return r
+
+        K.gemm_nt, K.gemm_tn = gemm_nt, gemm_tn
+
+    def summary(self):
+        agg = {}
+        for name, work, s, e in self.records:
+            ms = s.elapsed_time(e)
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += work
+        return {k: {"launches": v[0], "total_ms": v[1], "avg_us": 1e3 * v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
+                for k, v in agg.items()}
+
+
+def draw_randaugment_decisions(gen, n_transforms, batch, h, w):
+    return [{"op": int(gen.integers(0, 16)), "negate": bool(gen.uniform() < 0.5),
+             "centers": np.stack([gen.integers(0, h, size=batch), gen.integers(0, w, size=batch)], axis=1).astype(np.int32)}
+            for _ in range(n_transforms)]
+
+
+def cpu_baseline(cfg_kwargs, sample_images=8, steps=2):
+    """Oracle (CPU restatement of the TF2 reference) on the same workload shape: RandAugment(2,9) + normalise +
+    ViT-B/16 forward + CE + backward + AdamW, fp32 torch-CPU, bounded to a few images."""
+    from chambers_amd.engine import ViTConfig, init_keras_weights
+    from oracle import augment_ref as A
+    from oracle import rng_ref, vit_ref
+    cfg = ViTConfig(**cfg_kwargs)
+    kw = init_keras_weights(cfg, seed=1234)
+    p = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in kw.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v_ = {k: torch.zeros_like(v) for k, v in p.items()}
+    g = np.random.Generator(np.random.PCG64(0))
+    gd = np.random.Generator(np.random.PCG64(42))
+    images = g.integers(0, 256, size=(sample_images,) + cfg.image_size + (3,), dtype=np.uint8)
+    labels = torch.as_tensor(g.integers(0, cfg.classes, size=(sample_images,)))
+    n_sites = 1 + 3 * cfg.n_encoder_layers
+    times = []
+    for step in range(steps + 1):
+        t0 = time.perf_counter()
+        dec = draw_randaugment_decisions(gd, 2, sample_images, *cfg.image_size)
+        xa = A.rand_augment(images, 2, 9, dec)
+        x = torch.from_numpy(A.imagenet_normalize(xa, "tf"))
+        keys = {s: rng_ref.site_key(0, step, s) for s in range(n_sites)}
+        logits = vit_ref.vit_forward(p, x, cfg.as_oracle_cfg(), keys=keys)
+        loss = vit_ref.sparse_ce_from_logits(logits, labels)
+        grads = torch.autograd.grad(loss, list(p.values()))
+        with torch.no_grad():
+            vit_ref.adamw_step({k: v.data for k, v in p.items()}, dict(zip(p.keys(), grads)), m, v_, step + 1, weight_decay=0.01)
+        times.append(time.perf_counter() - t0)
+    best = float(np.median(times[1:]))
+    return {"value": sample_images / best, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d images x %d timed steps (1 warm-up) of the same train step, fp32 torch-CPU oracle" % (sample_images, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU")
+    ap.add_argument("--model", default="vitb16", choices=sorted(MODELS))
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-augment", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (one process per GPU)" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from chambers_amd import augmentations as aug
+    from chambers_amd import kernels as K
+    from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
+
+    timer = KernelTimer()
+    timer.wrap(K)
+
+    cfg_kwargs = dict(MODELS[args.model], dropout_rate=0.1, image_size=(args.image_size, args.image_size), classes=1000)
+    cfg = ViTConfig(**cfg_kwargs)
+    eng = ViTEngine(cfg, args.batch, training=True, seed=0)
+    eng.load_keras_weights(init_keras_weights(cfg, seed=1234))      # same init on every rank
+    g = np.random.Generator(np.random.PCG64(rank))                  # synthetic data: seed = rank
+    images = torch.as_tensor(g.integers(0, 256, size=(args.batch, args.image_size, args.image_size, 3), dtype=np.uint8), device="cuda")
+    labels = torch.as_tensor(g.integers(0, 1000, size=(args.batch,)), device="cuda")
+    gd = np.random.Generator(np.random.PCG64(42 + rank))            # augmentation decisions, host side
+    randaug = aug.RandAugment(2, 9)
+
+    def step():
+        x = images
+        if not args.no_augment:
+            x = randaug(images, training=True, decisions=draw_randaugment_decisions(gd, 2, args.batch, args.image_size, args.image_size))
+        return eng.train_step(x, labels, learning_rate=1e-3, weight_decay=0.05)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.mean().item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.batch * args.steps / elapsed
+        ks = timer.summary()
+        dom = max(ks, key=lambda k: ks[k]["total_ms"])
+        train_flops = 3.0 * forward_flops_per_image(cfg) * args.batch
+        out = {
+            "metric": "images/sec ViT-B/16 224^2 train step (synthetic)" if args.model == "vitb16" and args.image_size == 224
+            else "images/sec %s %d^2 train step (synthetic)" % (args.model, args.image_size),
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%s train step, batch %d/GPU, %dx%d, on-GPU RandAugment(n=2,m=9)%s, dropout 0.1, AdamW, dp%d"
+                       % (args.model, args.batch, args.image_size, args.image_size, " OFF" if args.no_augment else "", world),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ks[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ks[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_us": ks[dom]["avg_us"], "launches": ks[dom]["launches"]},
+            "step_tflops": train_flops / (ms_per_step * 1e-3) / 1e12,
+            "step_frac_of_mfma_peak": train_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "kernels": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 1), "launches": v["launches"],
+                            "total_ms": round(v["total_ms"], 2)} for k, v in ks.items()},
+            "final_loss": final_loss,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg_kwargs)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

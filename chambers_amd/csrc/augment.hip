@@ -589,8 +589,9 @@ const NormConst kTorch = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};
 extern "C" {
 
 int chb_aug_pointwise(const uint8_t* in, uint8_t* out, int64_t n_bytes, int op, float factor, int i0, int i1, void* stream) {
-    if (!in || !out || n_bytes < 0) return CHB_EINVAL;
+    if (n_bytes < 0) return CHB_EINVAL;
     if (n_bytes == 0) return CHB_OK;
+    if (!in || !out) return CHB_EINVAL;
     if (((uintptr_t)in & 3) || ((uintptr_t)out & 3)) return CHB_EINVAL;
     if (op == CHB_PW_COLOR && (n_bytes % 3) != 0) return CHB_EINVAL;
     PwParams pp{op, factor, i0, i1};
@@ -616,9 +617,9 @@ int chb_aug_pointwise(const uint8_t* in, uint8_t* out, int64_t n_bytes, int op, 
 
 int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, const float* transform_host8,
                    const float* transforms_dev, int per_image, int fill, void* stream) {
+    if (B == 0) return CHB_OK;
     if (!in || !out || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     if (!transform_host8 && !transforms_dev) return CHB_EINVAL;
-    if (B == 0) return CHB_OK;
     float t[8] = {1, 0, 0, 0, 1, 0, 0, 0};
     if (transform_host8) for (int i = 0; i < 8; ++i) t[i] = transform_host8[i];
     const int64_t total = (int64_t)B * H * ((W + 3) / 4);
@@ -631,9 +632,9 @@ int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, 
 
 int chb_aug_cutout(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, const int32_t* centers_dev, int mask_size,
                    int value, void* stream) {
+    if (B == 0) return CHB_OK;
     if (!in || !out || !centers_dev || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     if (mask_size < 0 || (mask_size & 1)) return CHB_EINVAL;  // tfa: mask_size must be even
-    if (B == 0) return CHB_OK;
     const int64_t total = (int64_t)B * H * ((W + 3) / 4);
     hipLaunchKernelGGL(cutout_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
                        centers_dev, mask_size / 2, value & 0xff);
@@ -651,8 +652,8 @@ static int slices_for(int64_t bytes_per_image, int B) {
 }
 
 int chb_aug_autocontrast(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, int32_t* workspace, void* stream) {
-    if (!in || !out || !workspace || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     if (B == 0) return CHB_OK;
+    if (!in || !out || !workspace || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nws = B * C * 2;
     hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, workspace, nws, 0);
@@ -664,8 +665,8 @@ int chb_aug_autocontrast(const uint8_t* in, uint8_t* out, int B, int H, int W, i
 }
 
 int chb_aug_equalize(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, int32_t* workspace, void* stream) {
-    if (!in || !out || !workspace || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     if (B == 0) return CHB_OK;
+    if (!in || !out || !workspace || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nws = B * C * 256;
     hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, workspace, nws, 1);
@@ -678,8 +679,8 @@ int chb_aug_equalize(const uint8_t* in, uint8_t* out, int B, int H, int W, int C
 }
 
 int chb_aug_sharpness(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, float factor, void* stream) {
-    if (!in || !out || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     if (B == 0) return CHB_OK;
+    if (!in || !out || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     const int64_t total = (int64_t)B * H * ((W + 3) / 4);
     const int grid = stream_grid(total);
     hipStream_t s = (hipStream_t)stream;
@@ -691,8 +692,8 @@ int chb_aug_sharpness(const uint8_t* in, uint8_t* out, int B, int H, int W, int 
 }
 
 int chb_normalize_u8(const uint8_t* in, float* out, int64_t n_pixels, int channels, int mode, void* stream) {
-    if (!in || !out || n_pixels < 0 || channels <= 0) return CHB_EINVAL;
     if (n_pixels == 0) return CHB_OK;
+    if (!in || !out || n_pixels < 0 || channels <= 0) return CHB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (mode == CHB_NORM_TF) {
         const int64_t nb = n_pixels * channels;
@@ -712,8 +713,8 @@ int chb_normalize_u8(const uint8_t* in, float* out, int64_t n_pixels, int channe
 }
 
 int chb_normalize_f32(const float* in, float* out, int64_t n_pixels, int channels, int mode, void* stream) {
-    if (!in || !out || n_pixels < 0 || channels != 3) return CHB_EINVAL;
     if (n_pixels == 0) return CHB_OK;
+    if (!in || !out || n_pixels < 0 || channels != 3) return CHB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int grid = stream_grid(n_pixels);
     if (mode == CHB_NORM_TF) hipLaunchKernelGGL((normalize_kernel<1, float>), dim3(grid), dim3(256), 0, s, in, out, n_pixels, kCaffe);
@@ -725,8 +726,8 @@ int chb_normalize_f32(const float* in, float* out, int64_t n_pixels, int channel
 }
 
 int chb_normalize_patchify_bf16(const uint8_t* in, void* out, int B, int H, int W, int patch, int mode, void* stream) {
-    if (!in || !out || B < 0 || H <= 0 || W <= 0 || patch <= 0 || (patch & 3)) return CHB_EINVAL;
     if (B == 0) return CHB_OK;
+    if (!in || !out || B < 0 || H <= 0 || W <= 0 || patch <= 0 || (patch & 3)) return CHB_EINVAL;
     const int gh = H / patch, gw = W / patch;
     if (gh == 0 || gw == 0) return CHB_EINVAL;
     const int64_t total = (int64_t)B * gh * patch * ((gw * patch) / 4);
@@ -742,8 +743,8 @@ int chb_normalize_patchify_bf16(const uint8_t* in, void* out, int B, int H, int 
 }
 
 int chb_patchify_f32_bf16(const float* in, void* out, int B, int H, int W, int patch, void* stream) {
-    if (!in || !out || B < 0 || H <= 0 || W <= 0 || patch <= 0 || (patch & 3)) return CHB_EINVAL;
     if (B == 0) return CHB_OK;
+    if (!in || !out || B < 0 || H <= 0 || W <= 0 || patch <= 0 || (patch & 3)) return CHB_EINVAL;
     const int gh = H / patch, gw = W / patch;
     if (gh == 0 || gw == 0) return CHB_EINVAL;
     const int64_t total = (int64_t)B * gh * patch * ((gw * patch) / 4);
