@@ -15,6 +15,7 @@
 // layers/transformer.py:72-77, models/backbones/vision_transformer.py:235-283.
 #include "common.hpp"
 #include "../../include/chambers_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +33,7 @@ struct GemmParams {
     int period;
     float drop_scale; uint32_t drop_thr; uint32_t drop_key;
     int tiles_m, tiles_n;
+    int stagger_ns;
 };
 
 // bijective XCD-aware remap: consecutive virtual ids (which share an A panel) stay on one XCD
@@ -66,59 +68,83 @@ __device__ __forceinline__ bf16x8_t frag_nt(const bf16_t* lds_tile, int r, int c
     return *reinterpret_cast<const bf16x8_t*>(lds_tile + off);
 }
 
-template <int EPI, int OUT>
-__device__ __forceinline__ void epilogue4(const GemmParams& p, int row, int col, float4_t acc) {
-    // row < M, col % 4 == 0, col < N
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
+// Epilogue of one 16-row MFMA tile row: this lane owns `row` and, for each of NB column tiles,
+// 4 consecutive columns col0 + 16*b .. +3.  All global loads of the row (residual / saved
+// pre-activation) are issued together before any store so they overlap instead of serialising.
+template <int EPI, int OUT, int NB, bool GUARD>
+__device__ __forceinline__ void epilogue_row(const GemmParams& p, int row, int col0, const float4_t* acc, const float4* bias4) {
+    float v[NB][4];
+    float4 r4[NB];
+    uint2 a2[NB];
     int64_t orow = row;
-    if (EPI == CHB_EPI_GELU) {
-        uint2 a;
-        a.x = pack_bf16x2(v[0], v[1]);
-        a.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(p.aux + (int64_t)row * p.ld_aux + col) = a;
+    const float* posrow = nullptr;
+    if (EPI == CHB_EPI_PATCH) {
+        const int b = row / p.period, pp = row - b * p.period;
+        orow = (int64_t)b * (p.period + 1) + 1 + pp;
+        posrow = p.resid + (int64_t)(1 + pp) * p.ld_resid;
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
-    } else if (EPI == CHB_EPI_DGELU) {
-        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (int64_t)row * p.ld_aux + col);
-        v[0] *= dgelu_f(bf16_to_f32((bf16_t)(a.x & 0xffff)));
-        v[1] *= dgelu_f(bf16_to_f32((bf16_t)(a.x >> 16)));
-        v[2] *= dgelu_f(bf16_to_f32((bf16_t)(a.y & 0xffff)));
-        v[3] *= dgelu_f(bf16_to_f32((bf16_t)(a.y >> 16)));
-    } else if (EPI == CHB_EPI_RESID || EPI == CHB_EPI_PATCH) {
-        const float* rs;
-        if (EPI == CHB_EPI_PATCH) {
-            const int b = row / p.period, pp = row - b * p.period;
-            orow = (int64_t)b * (p.period + 1) + 1 + pp;
-            rs = p.resid + (int64_t)(1 + pp) * p.ld_resid + col;
-            const float4 r4 = *reinterpret_cast<const float4*>(rs);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;  // + positional embedding, then dropout
-        }
-        if (p.drop_thr) {
-            const uint64_t e0 = (uint64_t)orow * (uint64_t)p.N + (uint64_t)col;  // even (N % 4 == 0)
-            bool k0, k1, k2, k3;
-            chb_keep2((uint32_t)(e0 >> 1), p.drop_key, p.drop_thr, k0, k1);
-            chb_keep2((uint32_t)(e0 >> 1) + 1u, p.drop_key, p.drop_thr, k2, k3);
-            v[0] = k0 ? v[0] * p.drop_scale : 0.0f;
-            v[1] = k1 ? v[1] * p.drop_scale : 0.0f;
-            v[2] = k2 ? v[2] * p.drop_scale : 0.0f;
-            v[3] = k3 ? v[3] * p.drop_scale : 0.0f;
-        }
-        if (EPI == CHB_EPI_RESID) {
-            const float4 r4 = *reinterpret_cast<const float4*>(p.resid + (int64_t)row * p.ld_resid + col);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    for (int b = 0; b < NB; ++b) {
+        const int col = col0 + 16 * b;
+        if (!GUARD || col < p.N) {
+            if (EPI == CHB_EPI_RESID) r4[b] = *reinterpret_cast<const float4*>(p.resid + (int64_t)row * p.ld_resid + col);
+            if (EPI == CHB_EPI_PATCH) r4[b] = *reinterpret_cast<const float4*>(posrow + col);
+            if (EPI == CHB_EPI_DGELU) a2[b] = *reinterpret_cast<const uint2*>(p.aux + (int64_t)row * p.ld_aux + col);
         }
     }
-    if (OUT == CHB_OUT_F32) {
-        *reinterpret_cast<float4*>((float*)p.C + orow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-        uint2 o;
-        o.x = pack_bf16x2(v[0], v[1]);
-        o.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>((bf16_t*)p.C + orow * p.ldc + col) = o;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = col0 + 16 * b;
+        if (GUARD && col >= p.N) continue;
+        v[b][0] = acc[b][0] + bias4[b].x; v[b][1] = acc[b][1] + bias4[b].y;
+        v[b][2] = acc[b][2] + bias4[b].z; v[b][3] = acc[b][3] + bias4[b].w;
+        if (EPI == CHB_EPI_GELU) {
+            uint2 a;
+            a.x = pack_bf16x2(v[b][0], v[b][1]);
+            a.y = pack_bf16x2(v[b][2], v[b][3]);
+            *reinterpret_cast<uint2*>(p.aux + (int64_t)row * p.ld_aux + col) = a;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[b][i] = gelu_f(v[b][i]);
+        } else if (EPI == CHB_EPI_DGELU) {
+            v[b][0] *= dgelu_f(bf16_to_f32((bf16_t)(a2[b].x & 0xffff)));
+            v[b][1] *= dgelu_f(bf16_to_f32((bf16_t)(a2[b].x >> 16)));
+            v[b][2] *= dgelu_f(bf16_to_f32((bf16_t)(a2[b].y & 0xffff)));
+            v[b][3] *= dgelu_f(bf16_to_f32((bf16_t)(a2[b].y >> 16)));
+        } else if (EPI == CHB_EPI_RESID || EPI == CHB_EPI_PATCH) {
+            if (EPI == CHB_EPI_PATCH) {  // + positional embedding, then dropout
+                v[b][0] += r4[b].x; v[b][1] += r4[b].y; v[b][2] += r4[b].z; v[b][3] += r4[b].w;
+            }
+            if (p.drop_thr) {
+                const uint64_t e0 = (uint64_t)orow * (uint64_t)p.N + (uint64_t)col;  // even (N % 4 == 0)
+                bool k0, k1, k2, k3;
+                chb_keep2((uint32_t)(e0 >> 1), p.drop_key, p.drop_thr, k0, k1);
+                chb_keep2((uint32_t)(e0 >> 1) + 1u, p.drop_key, p.drop_thr, k2, k3);
+                v[b][0] = k0 ? v[b][0] * p.drop_scale : 0.0f;
+                v[b][1] = k1 ? v[b][1] * p.drop_scale : 0.0f;
+                v[b][2] = k2 ? v[b][2] * p.drop_scale : 0.0f;
+                v[b][3] = k3 ? v[b][3] * p.drop_scale : 0.0f;
+            }
+            if (EPI == CHB_EPI_RESID) {
+                v[b][0] += r4[b].x; v[b][1] += r4[b].y; v[b][2] += r4[b].z; v[b][3] += r4[b].w;
+            }
+        }
+        if (OUT == CHB_OUT_F32) {
+            *reinterpret_cast<float4*>((float*)p.C + orow * p.ldc + col) = make_float4(v[b][0], v[b][1], v[b][2], v[b][3]);
+        } else {
+            uint2 o;
+            o.x = pack_bf16x2(v[b][0], v[b][1]);
+            o.y = pack_bf16x2(v[b][2], v[b][3]);
+            *reinterpret_cast<uint2*>((bf16_t*)p.C + orow * p.ldc + col) = o;
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void load_bias(const GemmParams& p, int col0, float4* bias4) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = col0 + 16 * b;
+        bias4[b] = (p.bias && col < p.N) ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -172,16 +198,333 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmParams p) {
         __syncthreads();
     }
 
+    float4 bias4[4];
+    load_bias<4>(p, n0 + wn * 64 + g * 4, bias4);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int row = m0 + wm * 64 + a * 16 + i;
-        if (row < p.M) {
+        if (row < p.M) epilogue_row<EPI, OUT, 4, true>(p, row, n0 + wn * 64 + g * 4, acc[a], bias4);
+    }
+}
+
+// ---- NT, persistent 256x256 tiles -------------------------------------------------------------
+// One 512-thread workgroup per CU (8 waves = 2(M) x 4(N), 128x64 outputs per wave) walks a list
+// of 256x256 output tiles.  Each 64-deep K-tile is four 16 KiB half-tiles (A rows 0-127 / 128-255,
+// B rows 0-127 / 128-255) in a 2-deep LDS ring (128 KiB).  A K-tile is computed in four phases of
+// 16 MFMAs (one 64x32 quadrant of the wave's output each); every phase also issues the two
+// global_load_lds of ONE half-tile of a later K-tile, so loads stay in flight across barriers and
+// across output-tile boundaries (the epilogue of tile i overlaps the loads of tile i+1):
+//   phase 1: read A(rows 0-63 of the wave), B(cols 0-31)   | stage A-half0 of step s+1
+//   phase 2: read B(cols 32-63)                            | stage A-half1 of step s+1
+//   phase 3: read A(rows 64-127)                           | stage B-half0 of step s+2
+//   phase 4: (B cols 0-31 kept in registers)               | stage B-half1 of step s+2, vmcnt(4)
+// The counted wait in phase 4 retires everything but the two B half-tiles of step s+2, i.e. all of
+// step s+1, which is first read one phase later (after the barriers).  A ring slot is restaged only
+// after the barrier that follows its last ds_read (B: end of phase 2, A: end of phase 3).
+// Epilogue of the persistent kernel: the wave's 128x64 fp32 accumulators go through a wave-private
+// 4 KiB LDS scratch, one 16x64 MFMA tile row at a time, and come back row-major (lane = 4 rows x 16
+// chunks of 4 columns), so that EVERY global access of the epilogue (residual / saved pre-activation
+// loads, output and aux stores) is 4 rows x 128..256 contiguous bytes per wave-instruction instead of
+// 16 rows x 32 bytes.  The scratch is XOR-swizzled (16-byte chunk ^ row) - conflict-free both ways.
+template <int EPI, int OUT, bool GUARD, int A0, int A1>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stage, int m_base, int n_base, float4_t (&acc)[8][4],
+                                                int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int cr = lane >> 4, c4 = lane & 15;
+    const int col = n_base + c4 * 4;
+    const bool colok = !GUARD || col < p.N;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && colok) bias = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int col = n0 + wn * 64 + b * 16 + g * 4;
-                if (col < p.N) epilogue4<EPI, OUT>(p, row, col, acc[a][b]);
+    for (int a = A0; a < A1; ++a) {
+        // inputs of this tile row first (they fly while the accumulators cross LDS)
+        float4 r4[4];
+        uint2 a2[4];
+        int64_t orow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = m_base + a * 16 + 4 * k + cr;
+            orow[k] = row;
+            const bool ok = colok && (!GUARD || row < p.M);
+            if (EPI == CHB_EPI_PATCH) {
+                const int bi = row / p.period, pp = row - bi * p.period;
+                orow[k] = (int64_t)bi * (p.period + 1) + 1 + pp;
+                if (ok) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(1 + pp) * p.ld_resid + col);
+            }
+            if (EPI == CHB_EPI_RESID && ok) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)row * p.ld_resid + col);
+            if (EPI == CHB_EPI_DGELU && ok) a2[k] = *reinterpret_cast<const uint2*>(p.aux + (int64_t)row * p.ld_aux + col);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<float4_t*>(stage + i * 64 + (((4 * b + g) ^ i) << 2)) = acc[a][b];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 4 * k + cr;
+            const float4_t t = *reinterpret_cast<const float4_t*>(stage + r * 64 + ((c4 ^ r) << 2));
+            const int row = m_base + a * 16 + r;
+            if (GUARD && !(colok && row < p.M)) continue;
+            float v[4] = {t[0] + bias.x, t[1] + bias.y, t[2] + bias.z, t[3] + bias.w};
+            if (EPI == CHB_EPI_GELU) {
+                uint2 pre;
+                pre.x = pack_bf16x2(v[0], v[1]);
+                pre.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(p.aux + (int64_t)row * p.ld_aux + col) = pre;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+            } else if (EPI == CHB_EPI_DGELU) {
+                v[0] *= dgelu_f(bf16_to_f32((bf16_t)(a2[k].x & 0xffff)));
+                v[1] *= dgelu_f(bf16_to_f32((bf16_t)(a2[k].x >> 16)));
+                v[2] *= dgelu_f(bf16_to_f32((bf16_t)(a2[k].y & 0xffff)));
+                v[3] *= dgelu_f(bf16_to_f32((bf16_t)(a2[k].y >> 16)));
+            } else if (EPI == CHB_EPI_RESID || EPI == CHB_EPI_PATCH) {
+                if (EPI == CHB_EPI_PATCH) {
+                    v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;
+                }
+                if (p.drop_thr) {
+                    const uint64_t e0 = (uint64_t)orow[k] * (uint64_t)p.N + (uint64_t)col;
+                    bool k0, k1, k2, k3;
+                    chb_keep2((uint32_t)(e0 >> 1), p.drop_key, p.drop_thr, k0, k1);
+                    chb_keep2((uint32_t)(e0 >> 1) + 1u, p.drop_key, p.drop_thr, k2, k3);
+                    v[0] = k0 ? v[0] * p.drop_scale : 0.0f;
+                    v[1] = k1 ? v[1] * p.drop_scale : 0.0f;
+                    v[2] = k2 ? v[2] * p.drop_scale : 0.0f;
+                    v[3] = k3 ? v[3] * p.drop_scale : 0.0f;
+                }
+                if (EPI == CHB_EPI_RESID) {
+                    v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;
+                }
+            }
+            if (p.stagger_ns == -1) { if (v[0] == 1.2345e30f) ((float*)p.C)[0] = v[1] + v[2] + v[3]; continue; }
+            if (OUT == CHB_OUT_F32) {
+                *reinterpret_cast<float4*>((float*)p.C + orow[k] * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>((bf16_t*)p.C + orow[k] * p.ldc + col) = o;
             }
         }
+    }
+}
+
+struct TileWalk {
+    int start, cnt, slot, stride;   // this workgroup's tiles: start + slot + j*stride, j = 0.. while < cnt
+    int tiles_n, ntk;
+};
+
+struct Cursor {   // (output tile, k-tile) position of a staging stream
+    int j, kt, m0, n0;
+    bool valid;
+};
+
+__device__ __forceinline__ void cursor_set(Cursor& c, const TileWalk& w, int j) {
+    c.j = j;
+    c.kt = 0;
+    const int li = w.slot + j * w.stride;
+    c.valid = li < w.cnt;
+    const int v = w.start + (c.valid ? li : 0);
+    const int tm = v / w.tiles_n;
+    c.m0 = tm * 256;
+    c.n0 = (v - tm * w.tiles_n) * 256;
+}
+
+__device__ __forceinline__ void cursor_next(Cursor& c, const TileWalk& w) {
+    if (++c.kt == w.ntk) cursor_set(c, w, c.j + 1);
+}
+
+// stage one 128-row half-tile (16 glds instructions over 8 waves: 2 per wave)
+__device__ __forceinline__ void stage_half(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0,
+                                           bf16_t* lds_half, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int inst = j * 8 + wave;
+        const int r = inst * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < max_row ? gr : max_row - 1;
+        glds16(g + (int64_t)gr * ld + k0 + c * 8, lds_half + inst * 512);
+    }
+}
+
+template <int EPI, int OUT>
+__global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
+    // 128 KiB operand ring [2][A0 A1 B0 B1][128 x 64] + 8 x 4 KiB wave-private epilogue scratch = the CU's whole 160 KiB
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * 8192 + 8 * 2048];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, i = lane & 15;
+
+    TileWalk w;
+    {
+        const int nb = (p.tiles_m < 0 ? -p.tiles_m : p.tiles_m) * p.tiles_n;
+        const int q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
+        w.start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        w.cnt = q + (x < r ? 1 : 0);
+        w.slot = blockIdx.x >> 3;
+        w.stride = gridDim.x >> 3;
+        w.tiles_n = p.tiles_n;
+        w.ntk = p.K / BK;
+    }
+    if (w.slot >= w.cnt) return;
+    if (p.stagger_ns > 0) {   // de-synchronise the CUs' epilogue bursts: phase group = slot & 3
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long ticks = (unsigned long long)((w.slot & 3) * p.stagger_ns) / 10;   // 100 MHz counter
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    const int nmy = (w.cnt - w.slot + w.stride - 1) / w.stride;
+    const int total = nmy * w.ntk;
+
+    // staging streams: A runs one step ahead of compute, B two steps ahead
+    Cursor ca, cb, cc;
+    cursor_set(cc, w, 0);
+    cursor_set(ca, w, 0);
+    cursor_set(cb, w, 0);
+    // prologue: all of step 0, B halves of step 1
+    stage_half(p.A, p.lda, ca.m0, p.M, 0, smem + 0 * 8192, wave, lane);
+    stage_half(p.A, p.lda, ca.m0 + 128, p.M, 0, smem + 1 * 8192, wave, lane);
+    stage_half(p.B, p.ldb, cb.n0, p.N, 0, smem + 2 * 8192, wave, lane);
+    stage_half(p.B, p.ldb, cb.n0 + 128, p.N, 0, smem + 3 * 8192, wave, lane);
+    cursor_next(ca, w);
+    cursor_next(cb, w);
+    if (cb.valid) {
+        stage_half(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, smem + (4 + 2) * 8192, wave, lane);
+        stage_half(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, smem + (4 + 3) * 8192, wave, lane);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    cursor_next(cb, w);
+    __builtin_amdgcn_s_barrier();
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int a_row = i;                        // + mq*64 + a*16 within the wave's A half
+    const int b_row = (wn & 1) * 64 + i;        // + nq*32 + b*16 within the wave's B half
+
+    for (int s = 0; s < total; ++s) {
+        bf16_t* ring = smem + (s & 1) * 4 * 8192;
+        bf16_t* nring = smem + ((s + 1) & 1) * 4 * 8192;
+        const bf16_t* As = ring + wm * 8192;
+        const bf16_t* Bs = ring + (2 + (wn >> 1)) * 8192;
+        bf16x8_t af[4][2], b0[2][2], b1[2][2];
+        const bool last_k = cc.kt == w.ntk - 1;
+        const bool interior = cc.m0 + 256 <= p.M && cc.n0 + 256 <= p.N;
+        float* stage = reinterpret_cast<float*>(smem + 2 * 4 * 8192) + wave * 1024;
+
+        // ---------------- phase 1: quadrant (rows 0-63, cols 0-31)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b0[b][ks] = frag_nt(Bs, b_row + b * 16, ks * 4 + g);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[a][ks] = frag_nt(As, a_row + a * 16, ks * 4 + g);
+        if (ca.valid) stage_half(p.A, p.lda, ca.m0, p.M, ca.kt * BK, nring + 0 * 8192, wave, lane);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[b][ks], af[a][ks], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // ---------------- phase 2: quadrant (rows 0-63, cols 32-63)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b1[b][ks] = frag_nt(Bs, b_row + 32 + b * 16, ks * 4 + g);
+        if (ca.valid) stage_half(p.A, p.lda, ca.m0 + 128, p.M, ca.kt * BK, nring + 1 * 8192, wave, lane);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[b][ks], af[a][ks], acc[a][2 + b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // rows 0-63 of the wave are final after phase 2 of the tile's last K-step: their stores fly under phases 3-4
+        if (last_k) {
+            if (p.tiles_m > 0) {
+                if (interior) epilogue_staged<EPI, OUT, false, 0, 4>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+                else epilogue_staged<EPI, OUT, true, 0, 4>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        // ---------------- phase 3: quadrant (rows 64-127, cols 32-63); B slots of this ring are free now
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[a][ks] = frag_nt(As, a_row + 64 + a * 16, ks * 4 + g);
+        if (cb.valid) stage_half(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, ring + 2 * 8192, wave, lane);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[4 + a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[b][ks], af[a][ks], acc[4 + a][2 + b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // ---------------- phase 4: quadrant (rows 64-127, cols 0-31); retire step s+1's loads
+        if (cb.valid) {
+            stage_half(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, ring + 3 * 8192, wave, lane);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[b][ks], af[a][ks], acc[4 + a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        cursor_next(ca, w);
+        cursor_next(cb, w);
+        // ---------------- end of an output tile: epilogue (later steps' loads keep flying)
+        if (last_k) {
+            if (p.tiles_m > 0) {
+                if (interior) epilogue_staged<EPI, OUT, false, 4, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+                else epilogue_staged<EPI, OUT, true, 4, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            }
+#pragma unroll
+            for (int a = 4; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        cursor_next(cc, w);
     }
 }
 
@@ -298,8 +641,221 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnParams p) {
     }
 }
 
+// ---- TN (wgrad), 256x256 output tile, one (tile, M-split) work item per 512-thread workgroup ----
+// Same 4-phase / half-tile ring as gemm_nt256_kernel; the operand half-tiles are [64 m][128 cols]
+// (256-byte rows) and every fragment is a pair of transposed LDS reads.  The reduction axis is the
+// long token axis M, split over workgroups so that tiles x splits ~ number of CUs; partial tiles are
+// added into dW with fp32 atomics issued as full 256-byte rows (staged through LDS).
+struct Tn256Params {
+    const bf16_t* X; int64_t ldx;
+    const bf16_t* Y; int64_t ldy;
+    float* W; int64_t ldw;
+    int M, Kd, Nd;
+    int tiles_k, tiles_n, splits, steps_per_split;
+};
+
+__device__ __forceinline__ void stage_half_tn(const bf16_t* __restrict__ g, int64_t ld, int m0, int col0, int ncols, bf16_t* lds_half,
+                                              int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int inst = j * 8 + wave;           // 16 instructions of 4 rows each
+        const int r = inst * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ swz_tn(r);
+        int gc = col0 + c * 8;
+        gc = gc < ncols ? gc : ncols - 8;
+        glds16(g + (int64_t)(m0 + r) * ld + gc, lds_half + inst * 512);
+    }
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * 8192 + 8 * 2048];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wk = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, i = lane & 15;
+    const int tiles = p.tiles_k * p.tiles_n;
+    const int split = blockIdx.x / tiles;
+    const int t = blockIdx.x - split * tiles;
+    const int tk = t / p.tiles_n, tn = t - tk * p.tiles_n;
+    const int k0 = tk * 256, n0 = tn * 256;
+    const int total_steps = p.M / 64;
+    const int s_begin = split * p.steps_per_split;
+    int s_end = s_begin + p.steps_per_split;
+    s_end = s_end < total_steps ? s_end : total_steps;
+    const int total = s_end - s_begin;
+    if (total <= 0) return;
+
+    // prologue: all of step 0, dY halves of step 1
+    stage_half_tn(p.X, p.ldx, s_begin * 64, k0, p.Kd, smem + 0 * 8192, wave, lane);
+    stage_half_tn(p.X, p.ldx, s_begin * 64, k0 + 128, p.Kd, smem + 1 * 8192, wave, lane);
+    stage_half_tn(p.Y, p.ldy, s_begin * 64, n0, p.Nd, smem + 2 * 8192, wave, lane);
+    stage_half_tn(p.Y, p.ldy, s_begin * 64, n0 + 128, p.Nd, smem + 3 * 8192, wave, lane);
+    if (total > 1) {
+        stage_half_tn(p.Y, p.ldy, (s_begin + 1) * 64, n0, p.Nd, smem + (4 + 2) * 8192, wave, lane);
+        stage_half_tn(p.Y, p.ldy, (s_begin + 1) * 64, n0 + 128, p.Nd, smem + (4 + 3) * 8192, wave, lane);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int ycol = (wn & 1) * 64;   // + nq*32 + b*16 within the wave's dY half
+
+    for (int s = 0; s < total; ++s) {
+        bf16_t* ring = smem + (s & 1) * 4 * 8192;
+        bf16_t* nring = smem + ((s + 1) & 1) * 4 * 8192;
+        const bf16_t* Xs = ring + wk * 8192;
+        const bf16_t* Ys = ring + (2 + (wn >> 1)) * 8192;
+        const bool have1 = s + 1 < total, have2 = s + 2 < total;
+        const int m1 = (s_begin + s + 1) * 64, m2 = (s_begin + s + 2) * 64;
+        bf16x8_t xf[4][2], y0[2][2], y1[2][2];
+
+        // phase 1: (kd 0-63, nd 0-31)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) y0[b][ks] = frag_tn(Ys, ks * 32, ycol + b * 16, g, i);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn(Xs, ks * 32, a * 16, g, i);
+        if (have1) stage_half_tn(p.X, p.ldx, m1, k0, p.Kd, nring + 0 * 8192, wave, lane);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][ks], xf[a][ks], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // phase 2: (kd 0-63, nd 32-63)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) y1[b][ks] = frag_tn(Ys, ks * 32, ycol + 32 + b * 16, g, i);
+        if (have1) stage_half_tn(p.X, p.ldx, m1, k0 + 128, p.Kd, nring + 1 * 8192, wave, lane);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][ks], xf[a][ks], acc[a][2 + b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // phase 3: (kd 64-127, nd 32-63); the dY slots of this ring are free now
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn(Xs, ks * 32, 64 + a * 16, g, i);
+        if (have2) stage_half_tn(p.Y, p.ldy, m2, n0, p.Nd, ring + 2 * 8192, wave, lane);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[4 + a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][ks], xf[a][ks], acc[4 + a][2 + b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // phase 4: (kd 64-127, nd 0-31); retire step s+1's loads
+        if (have2) {
+            stage_half_tn(p.Y, p.ldy, m2, n0 + 128, p.Nd, ring + 3 * 8192, wave, lane);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][ks], xf[a][ks], acc[4 + a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // acc[a][b][r]: kd = k0 + wk*128 + a*16 + i, nd = n0 + wn*64 + b*16 + 4g + r.  Stage one 16(kd) x 64(nd) tile row
+    // at a time and add it as 16 full 256-byte rows.
+    float* stage = reinterpret_cast<float*>(smem + 2 * 4 * 8192) + wave * 1024;
+    const int nd = n0 + wn * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<float4_t*>(stage + i * 64 + (((4 * b + g) ^ i) << 2)) = acc[a][b];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = stage[r * 64 + ((((lane >> 2) ^ r) << 2) | (lane & 3))];
+            const int kd = k0 + wk * 128 + a * 16 + r;
+            if (kd < p.Kd && nd < p.Nd) atomicAdd(p.W + (int64_t)kd * p.ldw + nd, v);
+        }
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// 0 = automatic, 1 = 128x128 tiles (one workgroup per tile), 2 = persistent 256x256 tiles
+int gemm_algo_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CHB_GEMM_ALGO");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <int EPI>
-int launch_nt(const GemmParams& p, int out_dtype, hipStream_t s) {
+int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
+    int algo = gemm_algo_override();
+    if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? 2 : 1;
+    if (algo == 2) {
+        p.tiles_m = chb_div_up(p.M, 256);
+        p.tiles_n = chb_div_up(p.N, 256);
+        if (getenv("CHB_DEBUG_NOEPI")) p.tiles_m = -p.tiles_m;  // timing experiment: skip the epilogue
+        { const char* e = getenv("CHB_GEMM_STAGGER_NS"); p.stagger_ns = e ? atoi(e) * (p.K / 64) : 0; if (getenv("CHB_DEBUG_NOSTORE")) p.stagger_ns = -1; }
+        int grid = num_cus() & ~7;
+        if (grid < 8) grid = 8;
+        const dim3 g(grid), block(512);
+        if (out_dtype == CHB_OUT_F32) hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_F32>), g, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_BF16>), g, block, 0, s, p);
+        return CHB_OK;
+    }
     const dim3 grid(p.tiles_m * p.tiles_n), block(256);
     if (out_dtype == CHB_OUT_F32) hipLaunchKernelGGL((gemm_nt_kernel<EPI, CHB_OUT_F32>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI, CHB_OUT_BF16>), grid, block, 0, s, p);
@@ -330,6 +886,7 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
     p.drop_scale = 1.0f / (1.0f - drop_rate);
     p.drop_key = drop_key;
     p.tiles_m = chb_div_up(M, BM); p.tiles_n = chb_div_up(N, BN);
+    p.stagger_ns = 0;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case CHB_EPI_NONE: launch_nt<CHB_EPI_NONE>(p, out_dtype, s); break;
@@ -349,6 +906,26 @@ int chb_gemm_tn(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* 
     if (M == 0) return CHB_OK;
     if (M % 64 != 0 || (Kd & 7) || (Nd & 7) || (ldx & 7) || (ldy & 7)) return CHB_EUNSUPPORTED;
     if (((uintptr_t)X & 15) || ((uintptr_t)dY & 15)) return CHB_EINVAL;
+    {
+        int algo = gemm_algo_override();
+        if (algo == 0) algo = (M >= 4096 && Kd >= 128 && Nd >= 128) ? 2 : 1;
+        if (algo == 2) {
+            Tn256Params q;
+            q.X = (const bf16_t*)X; q.ldx = ldx; q.Y = (const bf16_t*)dY; q.ldy = ldy; q.W = dW; q.ldw = ldw;
+            q.M = M; q.Kd = Kd; q.Nd = Nd;
+            q.tiles_k = chb_div_up(Kd, 256); q.tiles_n = chb_div_up(Nd, 256);
+            const int tiles = q.tiles_k * q.tiles_n;
+            const int steps = M / 64;
+            int splits = num_cus() / tiles;          // one work item per CU
+            if (splits < 1) splits = 1;
+            if (splits > steps) splits = steps;
+            q.steps_per_split = chb_div_up(steps, splits);
+            q.splits = chb_div_up(steps, q.steps_per_split);
+            hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * q.splits), dim3(512), 0, (hipStream_t)stream, q);
+            CHB_LAUNCH_CHECK();
+            return CHB_OK;
+        }
+    }
     TnParams p;
     p.X = (const bf16_t*)X; p.ldx = ldx; p.Y = (const bf16_t*)dY; p.ldy = ldy; p.W = dW; p.ldw = ldw;
     p.M = M; p.Kd = Kd; p.Nd = Nd;
