@@ -5,7 +5,7 @@
 //   forward : S^T = K.Q^T (keys on MFMA rows -> a lane holds ONE query's scores, softmax is an
 //             in-lane reduction + 2 shuffles), P^T feeds the P.V MFMA straight from the
 //             accumulators (k-order permuted on both operands), V^T via ds_read_b64_tr_b16.
-//   backward: each wave owns 1/4 of the key tiles and keeps dK^T/dV^T for them in registers
+//   backward: each of 8 waves owns 1/8 of the key tiles and keeps dK^T/dV^T for them in registers
 //             across all query blocks; dS goes once through LDS for dQ.  No atomics.
 // Dropout on the probabilities uses the counter hash of common.hpp, element index
 // ((b*H + h)*N + q)*N + k, so forward and backward regenerate the same mask.
@@ -52,10 +52,10 @@ __device__ __forceinline__ bf16x8_t pack8(const float4_t& a, const float4_t& b) 
 }
 
 // stage rows [0, nrows_pad) x 64 of one head slice into an LDS image (zero rows >= n_valid)
-template <bool VSWZ>
+template <bool VSWZ, int NTHREADS = 256>
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64_t row_stride, int n_valid, int nrows_pad,
                                            bf16_t* img, int tid) {
-    for (int id = tid; id < nrows_pad * 8; id += 256) {
+    for (int id = tid; id < nrows_pad * 8; id += NTHREADS) {
         const int r = id >> 3, c = id & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (r < n_valid) v = *reinterpret_cast<const uint4*>(src + (int64_t)r * row_stride + c * 8);
@@ -66,7 +66,7 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64
 
 // ------------------------------------------------------------------------------------ forward
 template <int NTP>  // pairs of 16-key tiles; padded key count = 32 * NTP
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse_out,
+__global__ void __launch_bounds__(256, NTP <= 7 ? 2 : 1) attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse_out,
                                                        int N, int H, float scale_log2, float drop_scale, uint32_t drop_thr,
                                                        uint32_t drop_key) {
     constexpr int NKP = 32 * NTP, NT = 2 * NTP;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16_t* __restrict_
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[t][r] = exp2f(s[t][r] - mx);
+                s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mx);
                 sum += s[t][r];
             }
         sum += __shfl_xor(sum, 16, 64);
@@ -124,9 +124,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16_t* __restrict_
         const int q = q0 + i;
         if (g == 0 && q < N) lse_out[(int64_t)bh * N + q] = (mx + log2f(sum)) * 0.69314718055994530942f;
         const uint64_t ebase = ((uint64_t)bh * (uint64_t)N + (uint64_t)min(q, N - 1)) * (uint64_t)N;
+        // dropout on the (still unnormalised) probabilities; 1/sum and 1/(1-rate) are applied to O (16 values) instead
+        if (drop_thr) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (drop_thr) {
+            for (int t = 0; t < NT; ++t) {
                 const uint64_t e0 = ebase + (uint64_t)(16 * t + 4 * g);
                 const uint32_t c0 = (uint32_t)(e0 >> 1), odd = (uint32_t)(e0 & 1);
                 const uint32_t h0 = chb_hash32(c0 ^ drop_key), h1 = chb_hash32((c0 + 1u) ^ drop_key), h2 = chb_hash32((c0 + 2u) ^ drop_key);
@@ -136,13 +137,11 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t u = odd ? uo[r] : ue[r];
-                    s[t][r] = (u >= drop_thr) ? s[t][r] * inv * drop_scale : 0.f;
+                    s[t][r] = (u >= drop_thr) ? s[t][r] : 0.f;
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] *= inv;
             }
         }
+        const float oscale = drop_thr ? inv * drop_scale : inv;
         // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; k-slot (g, j): j<4 -> key 32u+4g+j, j>=4 -> key 32u+16+4g+(j-4)
         float4_t oacc[4];
 #pragma unroll
@@ -161,8 +160,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 w;
-                w.x = pack_bf16x2(oacc[dt][0], oacc[dt][1]);
-                w.y = pack_bf16x2(oacc[dt][2], oacc[dt][3]);
+                w.x = pack_bf16x2(oacc[dt][0] * oscale, oacc[dt][1] * oscale);
+                w.y = pack_bf16x2(oacc[dt][2] * oscale, oacc[dt][3] * oscale);
                 *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
             }
         }
@@ -173,11 +172,11 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const bf16_t* __restrict_
 // LDS: K, V, Q, dO images [NP][64] (row-read swizzle; transposed reads take a 2-way conflict),
 // dS double buffer [2][32][NP + 8], lse*log2e and delta per query.
 template <int NTP>
-__global__ void __launch_bounds__(256) attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+__global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, float scale,
                                                        float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key) {
     constexpr int NP = 32 * NTP, NT = 2 * NTP;
-    constexpr int MT = (NT + 3) / 4;   // key tiles owned by one wave (wave w: tiles w, w+4, ...)
+    constexpr int MT = (NT + 7) / 8;   // key tiles owned by one wave (wave w of 8: tiles w, w+8, ...)
     constexpr int DSLD = NP + 8;       // dS row stride (elements)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
@@ -197,18 +196,18 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const bf16_t* __restrict_
     const bf16_t* obase = o + (int64_t)b * N * Dm + h * HD;
     const bf16_t* gbase = d_o + (int64_t)b * N * Dm + h * HD;
 
-    stage_rows<false>(base, D3, N, NP, Qs, tid);
-    stage_rows<false>(base + Dm, D3, N, NP, Ks, tid);
-    stage_rows<false>(base + 2 * Dm, D3, N, NP, Vs, tid);
+    stage_rows<false, 512>(base, D3, N, NP, Qs, tid);
+    stage_rows<false, 512>(base + Dm, D3, N, NP, Ks, tid);
+    stage_rows<false, 512>(base + 2 * Dm, D3, N, NP, Vs, tid);
     // dO image + delta[q] = sum_d dO*O (8 threads per row, one 16-byte chunk each)
-    for (int id = tid; id < NP * 8; id += 256) {
+    for (int id = tid; id < ((NP * 8 + 511) & ~511); id += 512) {   // full waves only: the reduction below shuffles
         const int r = id >> 3, c = id & 7;
         uint4 gv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
-        if (r < N) {
+        if (r < N && r < NP) {
             gv = *reinterpret_cast<const uint4*>(gbase + (int64_t)r * Dm + c * 8);
             ov = *reinterpret_cast<const uint4*>(obase + (int64_t)r * Dm + c * 8);
         }
-        *reinterpret_cast<uint4*>(Gs + r * HD + ((c ^ swz_row(r)) << 3)) = gv;
+        if (r < NP) *reinterpret_cast<uint4*>(Gs + r * HD + ((c ^ swz_row(r)) << 3)) = gv;
         const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
         float d = 0.f;
 #pragma unroll
@@ -219,9 +218,9 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const bf16_t* __restrict_
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
         d += __shfl_xor(d, 4, 64);
-        if (c == 0) delta[r] = d;
+        if (c == 0 && r < NP) delta[r] = d;
     }
-    for (int r = tid; r < NP; r += 256) lse2[r] = r < N ? lse[(int64_t)bh * N + r] * 1.44269504088896340736f : INFINITY;
+    for (int r = tid; r < NP; r += 512) lse2[r] = r < N ? lse[(int64_t)bh * N + r] * 1.44269504088896340736f : INFINITY;
     __syncthreads();
 
     float4_t dk[4][MT], dv[4][MT];
@@ -255,7 +254,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const bf16_t* __restrict_
             }
 #pragma unroll
         for (int c = 0; c < MT; ++c) {
-            const int t = wave + 4 * c;
+            const int t = wave + 8 * c;
             if (t < NT) {  // wave-uniform
                 const int key = 16 * t + i;
                 float4_t pd[2], ds[2];
@@ -271,7 +270,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int q = q0 + 16 * qs + 4 * g + r;
-                        float p = (key < N) ? exp2f(sv[r] * scale_log2 - l2[qs][r]) : 0.f;
+                        float p = (key < N) ? __builtin_amdgcn_exp2f(sv[r] * scale_log2 - l2[qs][r]) : 0.f;
                         float keepc = 1.0f;
                         if (drop_thr) {
                             const uint64_t e = ((uint64_t)bh * (uint64_t)N + (uint64_t)min(q, N - 1)) * (uint64_t)N + (uint64_t)min(key, N - 1);
@@ -299,13 +298,13 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const bf16_t* __restrict_
             }
         }
         __syncthreads();
-        // ---- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; wave w owns d-tile w
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
+        // ---- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; wave w owns query sub-tile w>>2, d-tile w&3
+        {
+            const int qs = wave >> 2, dtw = wave & 3;
             float4_t dq = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < NTP; ++u) {
-                const bf16x8_t kt = lds_tr_frag<false>(Ks, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * wave, i);  // A[row d][k = key 32u+8g+j]
+                const bf16x8_t kt = lds_tr_frag<false>(Ks, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * dtw, i);  // A[row d][k = key 32u+8g+j]
                 const bf16x8_t sb = *reinterpret_cast<const bf16x8_t*>(dSb + (16 * qs + i) * DSLD + 32 * u + 8 * g);  // B[k][col q]
                 dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, sb, dq, 0, 0, 0);
             }
@@ -314,14 +313,14 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const bf16_t* __restrict_
                 uint2 w;
                 w.x = pack_bf16x2(dq[0], dq[1]);
                 w.y = pack_bf16x2(dq[2], dq[3]);
-                *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * wave + 4 * g) = w;
+                *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * dtw + 4 * g) = w;
             }
         }
     }
     // dK^T / dV^T accumulators: lane (g,i) reg r = [d = 16dt + 4g + r][key = 16t + i]
 #pragma unroll
     for (int c = 0; c < MT; ++c) {
-        const int t = wave + 4 * c;
+        const int t = wave + 8 * c;
         const int key = 16 * t + i;
         if (t < NT && key < N) {
             bf16_t* kp = dqkv + ((int64_t)b * N + key) * D3 + Dm + h * HD;
@@ -382,7 +381,7 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
     const float scale_log2 = 1.44269504088896340736f * scale;
     const float ds = 1.0f / (1.0f - drop_rate);
     const uint32_t thr = drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u;
-    const dim3 grid(B * H), block(256);
+    const dim3 grid(B * H), block(512);
     hipStream_t s = (hipStream_t)stream;
 #define CHB_BWD(NTP)                                                                                                             \
     do {                                                                                                                         \

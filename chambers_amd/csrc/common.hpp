@@ -89,8 +89,8 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void erf_parts(float x, float& erf_abs, float& expo) {
     // z = |x| / sqrt(2); erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z)
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    expo = __expf(-z * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);          // v_rcp_f32 (1 ulp)
+    expo = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);        // v_exp_f32
     float poly = 1.061405429f;
     poly = poly * t - 1.453152027f;
     poly = poly * t + 1.421413741f;
@@ -108,6 +108,14 @@ __device__ __forceinline__ float dgelu_f(float x) {
     erf_parts(x, e, ex);
     const float cdf = 0.5f * (1.0f + copysignf(e, x));
     return cdf + x * 0.39894228040143267794f * ex;   // ex = exp(-x^2/2)
+}
+// both at once (shared erf / exp): y = gelu(x), d = gelu'(x)
+__device__ __forceinline__ void gelu_both(float x, float& y, float& d) {
+    float e, ex;
+    erf_parts(x, e, ex);
+    const float cdf = 0.5f * (1.0f + copysignf(e, x));
+    y = x * cdf;
+    d = cdf + x * 0.39894228040143267794f * ex;
 }
 
 static inline int chb_div_up(long a, long b) { return (int)((a + b - 1) / b); }

@@ -99,17 +99,18 @@ __device__ __forceinline__ void epilogue_row(const GemmParams& p, int row, int c
         v[b][0] = acc[b][0] + bias4[b].x; v[b][1] = acc[b][1] + bias4[b].y;
         v[b][2] = acc[b][2] + bias4[b].z; v[b][3] = acc[b][3] + bias4[b].w;
         if (EPI == CHB_EPI_GELU) {
-            uint2 a;
-            a.x = pack_bf16x2(v[b][0], v[b][1]);
-            a.y = pack_bf16x2(v[b][2], v[b][3]);
-            *reinterpret_cast<uint2*>(p.aux + (int64_t)row * p.ld_aux + col) = a;
+            float d[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[b][i] = gelu_f(v[b][i]);
+            for (int i = 0; i < 4; ++i) gelu_both(v[b][i], v[b][i], d[i]);
+            uint2 a;
+            a.x = pack_bf16x2(d[0], d[1]);
+            a.y = pack_bf16x2(d[2], d[3]);
+            *reinterpret_cast<uint2*>(p.aux + (int64_t)row * p.ld_aux + col) = a;
         } else if (EPI == CHB_EPI_DGELU) {
-            v[b][0] *= dgelu_f(bf16_to_f32((bf16_t)(a2[b].x & 0xffff)));
-            v[b][1] *= dgelu_f(bf16_to_f32((bf16_t)(a2[b].x >> 16)));
-            v[b][2] *= dgelu_f(bf16_to_f32((bf16_t)(a2[b].y & 0xffff)));
-            v[b][3] *= dgelu_f(bf16_to_f32((bf16_t)(a2[b].y >> 16)));
+            v[b][0] *= bf16_to_f32((bf16_t)(a2[b].x & 0xffff));
+            v[b][1] *= bf16_to_f32((bf16_t)(a2[b].x >> 16));
+            v[b][2] *= bf16_to_f32((bf16_t)(a2[b].y & 0xffff));
+            v[b][3] *= bf16_to_f32((bf16_t)(a2[b].y >> 16));
         } else if (EPI == CHB_EPI_RESID || EPI == CHB_EPI_PATCH) {
             if (EPI == CHB_EPI_PATCH) {  // + positional embedding, then dropout
                 v[b][0] += r4[b].x; v[b][1] += r4[b].y; v[b][2] += r4[b].z; v[b][3] += r4[b].w;
@@ -264,17 +265,18 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
             if (GUARD && !(colok && row < p.M)) continue;
             float v[4] = {t[0] + bias.x, t[1] + bias.y, t[2] + bias.z, t[3] + bias.w};
             if (EPI == CHB_EPI_GELU) {
-                uint2 pre;
-                pre.x = pack_bf16x2(v[0], v[1]);
-                pre.y = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(p.aux + (int64_t)row * p.ld_aux + col) = pre;
+                float d[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], d[e]);
+                uint2 der;
+                der.x = pack_bf16x2(d[0], d[1]);
+                der.y = pack_bf16x2(d[2], d[3]);
+                *reinterpret_cast<uint2*>(p.aux + (int64_t)row * p.ld_aux + col) = der;
             } else if (EPI == CHB_EPI_DGELU) {
-                v[0] *= dgelu_f(bf16_to_f32((bf16_t)(a2[k].x & 0xffff)));
-                v[1] *= dgelu_f(bf16_to_f32((bf16_t)(a2[k].x >> 16)));
-                v[2] *= dgelu_f(bf16_to_f32((bf16_t)(a2[k].y & 0xffff)));
-                v[3] *= dgelu_f(bf16_to_f32((bf16_t)(a2[k].y >> 16)));
+                v[0] *= bf16_to_f32((bf16_t)(a2[k].x & 0xffff));
+                v[1] *= bf16_to_f32((bf16_t)(a2[k].x >> 16));
+                v[2] *= bf16_to_f32((bf16_t)(a2[k].y & 0xffff));
+                v[3] *= bf16_to_f32((bf16_t)(a2[k].y >> 16));
             } else if (EPI == CHB_EPI_RESID || EPI == CHB_EPI_PATCH) {
                 if (EPI == CHB_EPI_PATCH) {
                     v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;

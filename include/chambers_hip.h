@@ -43,8 +43,8 @@ extern "C" {
 
 /* GEMM epilogue modes (chb_gemm_nt) */
 #define CHB_EPI_NONE 0   /* C = acc (+bias) */
-#define CHB_EPI_GELU 1   /* aux = bf16(acc+bias); C = gelu(acc+bias)      layers/transformer.py:42-44 */
-#define CHB_EPI_DGELU 2  /* C = acc * gelu'(aux)                          backward of the above */
+#define CHB_EPI_GELU 1   /* x = acc+bias; C = gelu(x); aux = bf16(gelu'(x))   layers/transformer.py:42-44 */
+#define CHB_EPI_DGELU 2  /* C = acc * aux                                     backward of the above */
 #define CHB_EPI_RESID 3  /* C = resid + dropout(acc+bias)                 layers/transformer.py:57-58,69,76 */
 #define CHB_EPI_PATCH 4  /* C[row'] = dropout(acc+bias+pos[1+p])          vision_transformer.py:235-261 */
 
@@ -102,8 +102,8 @@ int chb_dropout_mask(uint8_t* out, int64_t n, float rate, uint32_t key, void* st
 /* C[M,N] = epilogue(A[M,K] . B[N,K]^T): bf16 operands, both K-contiguous, fp32 accumulate on
  * MFMA (Dense / einsum projections: layers/attention.py:113-125, layers/transformer.py:72-77,
  * vision_transformer.py:235-283).  bias fp32 [N] or NULL.  out_dtype CHB_OUT_BF16|CHB_OUT_F32.
- *  GELU : aux (bf16 [M,ld_aux]) receives the pre-activation.
- *  DGELU: aux is the saved pre-activation.
+ *  GELU : aux (bf16 [M,ld_aux]) receives gelu'(acc+bias) (the erf/exp are shared with the forward value).
+ *  DGELU: aux is that saved derivative.
  *  RESID: resid fp32 [M,ld_resid] (may alias C); dropout (rate,key) on acc+bias, element
  *         index row*N+col.
  *  PATCH: rows are (image b, patch p) = row / period, row % period; written to row

@@ -91,9 +91,22 @@ def multi_head_attention(x, p, prefix, num_heads, rate, key, bf16):
     query, value, keyt = _bf(query, bf16), _bf(value, bf16), _bf(keyt, bf16)
     # ScaledAttention._calculate_scores (layers/attention.py:13-23): matmul, THEN divide
     scores = torch.matmul(query, keyt.transpose(-1, -2)) / math.sqrt(head_dim)
-    weights = torch.softmax(scores, dim=-1)
-    weights = _drop(weights, rate, key)
-    attn = torch.matmul(_bf(weights, bf16), value)
+    if not bf16:
+        weights = torch.softmax(scores, dim=-1)
+        weights = _drop(weights, rate, key)
+        attn = torch.matmul(weights, value)
+    else:
+        # same mathematics with the build's rounding points: the un-normalised exponentials (masked by the
+        # dropout keep-mask) are rounded to bf16 for the P.V product; 1/sum and 1/(1-rate) scale the fp32 result
+        mx = scores.max(dim=-1, keepdim=True).values
+        pt = torch.exp(scores - mx)
+        denom = pt.sum(dim=-1, keepdim=True)
+        scale = 1.0
+        if rate != 0.0 and key is not None:
+            keep = rng_ref.keep_mask(pt.numel(), key, rate).reshape(tuple(pt.shape))
+            pt = pt * torch.from_numpy(keep).to(pt.dtype)
+            scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
+        attn = torch.matmul(_bf(pt, True), value) * (scale / denom)
     attn = _bf(attn, bf16)
     return torch.einsum("bnth,ndh->btd", attn, _bf(wp, bf16)) + bp
 
