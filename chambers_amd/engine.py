@@ -379,13 +379,14 @@ class ViTEngine:
         step = self.opt_step
         return rate, (lambda site: rng.site_key(self.seed, step, site))
 
-    def embed(self, images_u8, training):
+    def embed(self, images_u8, training, prepatched=False):
         """normalise + patchify + patch-embedding GEMM (+bias +pos, dropout) + cls row -> xs[0]."""
         cfg = self.cfg
         rate, key = self._keys(training)
-        if tuple(images_u8.shape) != (self.B, cfg.image_size[0], cfg.image_size[1], 3):
-            raise ValueError("expected images of shape %s, got %s" % ((self.B,) + cfg.image_size + (3,), tuple(images_u8.shape)))
-        K.normalize_patchify(images_u8, cfg.patch_size, cfg.norm_mode, out=self.patches)
+        if not prepatched:
+            if tuple(images_u8.shape) != (self.B, cfg.image_size[0], cfg.image_size[1], 3):
+                raise ValueError("expected images of shape %s, got %s" % ((self.B,) + cfg.image_size + (3,), tuple(images_u8.shape)))
+            K.normalize_patchify(images_u8, cfg.patch_size, cfg.norm_mode, out=self.patches)
         x0 = self.xs[0]
         K.gemm_nt(self.patches, self.wbt("patch_embeddings/embedding/kernel"), x0, m=self.Mpatch,
                   bias=self.p("patch_embeddings/embedding/bias"), epilogue=K.EPI_PATCH, resid=self.p("pos_embedding/embeddings"),
@@ -412,12 +413,13 @@ class ViTEngine:
         K.gemm_nt(a["u"], self.wbt(pre + "dense2/kernel"), x_out, m=M, bias=self.p(pre + "dense2/bias"), epilogue=K.EPI_RESID,
                   resid=a["xmid"], drop_rate=rate, drop_key=key(rng.site_mlp(l)))
 
-    def forward(self, images_u8, training=None):
-        """Returns logits fp32 [B, classes] (a view of the padded logits buffer)."""
+    def forward(self, images_u8, training=None, prepatched=False):
+        """Returns logits fp32 [B, classes] (a view of the padded logits buffer).  prepatched=True: self.patches
+        already holds the bf16 patch rows (float32-input path of the Keras-style Model)."""
         training = self.training if training is None else training
         cfg = self.cfg
         L = cfg.n_encoder_layers
-        x = self.embed(images_u8, training)
+        x = self.embed(images_u8, training, prepatched)
         for l in range(L):
             if self.training:
                 x_out, a = self.xs[l + 1], self.acts[l]

@@ -1,0 +1,132 @@
+"""chambers.layers.transformer on MI355X: EncoderLayer / Encoder (reference chambers/layers/transformer.py:8-77,
+256-314).  DecoderLayer / Decoder are not on the ViT path and are not built.
+
+The standalone layers execute the same HIP kernels as the whole-model engine, one call per op; the residual
+stream is float32 [B, T, D]."""
+import torch
+
+from .. import kernels as K
+from .._keras_like import Layer, register_keras_serializable
+from ..activations import gelu
+from .attention import MultiHeadAttention
+from .core import Dense, Dropout, LayerNormalization, _bf16, _next_key
+
+
+@register_keras_serializable(package="Chambers")
+class EncoderLayer(Layer):
+    _site = 9300
+
+    def __init__(self, embed_dim=512, num_heads=8, ff_dim=2048, dense_kernel_initializer="glorot_uniform", attention_dropout_rate=0.1,
+                 dense_dropout_rate=0.1, norm_epsilon=1e-6, pre_norm=False, **kwargs):
+        super(EncoderLayer, self).__init__(**kwargs)
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.ff_dim = ff_dim
+        self.dense_kernel_initializer = dense_kernel_initializer
+        self.attention_dropout_rate = attention_dropout_rate
+        self.dense_dropout_rate = dense_dropout_rate
+        self.norm_epsilon = norm_epsilon
+        self.pre_norm = pre_norm
+        self.multi_head_attention = MultiHeadAttention(head_dim=embed_dim // num_heads, num_heads=num_heads,
+                                                       dense_kernel_initializer=dense_kernel_initializer,
+                                                       dropout_rate=attention_dropout_rate, causal=False)
+        self.dropout1 = Dropout(dense_dropout_rate)
+        self.norm1 = LayerNormalization(epsilon=norm_epsilon)
+        self.dense1 = Dense(ff_dim, activation=gelu, kernel_initializer=dense_kernel_initializer)
+        self.dense2 = Dense(embed_dim, kernel_initializer=dense_kernel_initializer)
+        self.dropout2 = Dropout(dense_dropout_rate)
+        self.norm2 = LayerNormalization(epsilon=norm_epsilon)
+        self.supports_masking = True
+
+    def _sublayers(self):
+        # weight order = creation order of the reference: MHA (8), norm1 (2), dense1 (2), dense2 (2), norm2 (2)
+        return [self.multi_head_attention, self.norm1, self.dense1, self.dense2, self.norm2]
+
+    def build(self, input_shape):
+        shape = tuple(input_shape)
+        self.multi_head_attention.build([shape, shape, shape]); self.multi_head_attention.built = True
+        self.norm1.build(shape); self.norm1.built = True
+        self.dense1.build(shape); self.dense1.built = True
+        self.dense2.build(shape[:-1] + (self.ff_dim,)); self.dense2.built = True
+        self.norm2.build(shape); self.norm2.built = True
+
+    def call(self, inputs, mask=None, training=None, keys=None, **kwargs):
+        if mask is not None:
+            raise ValueError("attention masks are not on the ViT path")
+        if not self.pre_norm:
+            raise NotImplementedError("post-norm EncoderLayer (pre_norm=False) is not on the ViT path (vision_transformer.py:269); "
+                                      "the MI355X kernels implement the pre-norm block")
+        keys = keys or {}
+        rate = self.dense_dropout_rate if training else 0.0
+        x = inputs.to(torch.float32).contiguous()
+        b, t, d = x.shape
+        x2 = x.reshape(b * t, d)
+        h = self.norm1(x)
+        a = self.multi_head_attention([h, h, h], training=training, key=keys.get("attn"))
+        # x = x + dropout1(attn): fused as the residual epilogue's element-wise form
+        a = self.dropout1(a, training=training, key=keys.get("proj"))
+        x2 = x2 + a.reshape(b * t, d)
+        h2 = self.norm2(x2.reshape(b, t, d))
+        u = self.dense1(h2)
+        # dense2 with the residual + dropout fused into the GEMM epilogue
+        out = torch.empty((b * t, d), dtype=torch.float32, device=x.device)
+        K.gemm_nt(_bf16(u.reshape(b * t, self.ff_dim)).contiguous(), self.dense2._cache.get(self.dense2, self.dense2.kernel), out,
+                  bias=self.dense2.bias.value, epilogue=K.EPI_RESID, resid=x2.contiguous(), drop_rate=rate,
+                  drop_key=(keys.get("mlp") or _next_key(self._site)) if rate else 0)
+        return out.reshape(b, t, d)
+
+    def get_config(self):
+        config = {"embed_dim": self.embed_dim, "num_heads": self.num_heads, "ff_dim": self.ff_dim,
+                  "dense_kernel_initializer": self.dense_kernel_initializer, "attention_dropout_rate": self.attention_dropout_rate,
+                  "dense_dropout_rate": self.dense_dropout_rate, "norm_epsilon": self.norm_epsilon, "pre_norm": self.pre_norm}
+        return dict(list(super(EncoderLayer, self).get_config().items()) + list(config.items()))
+
+
+@register_keras_serializable(package="Chambers")
+class Encoder(Layer):
+    def __init__(self, embed_dim, num_heads, ff_dim, num_layers, dense_kernel_initializer="glorot_uniform", attention_dropout_rate=0.1,
+                 dense_dropout_rate=0.1, norm_epsilon=1e-6, pre_norm=False, norm_output=False, **kwargs):
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.ff_dim = ff_dim
+        self.num_layers = num_layers
+        self.dense_kernel_initializer = dense_kernel_initializer
+        self.attention_dropout_rate = attention_dropout_rate
+        self.dense_dropout_rate = dense_dropout_rate
+        self.norm_epsilon = norm_epsilon
+        self.pre_norm = pre_norm
+        self.norm_output = norm_output
+        self.norm_layer = LayerNormalization(epsilon=norm_epsilon) if norm_output else None
+        self.layers = []
+        self.supports_masking = True
+        super(Encoder, self).__init__(**kwargs)
+
+    def _sublayers(self):
+        return list(self.layers) + ([self.norm_layer] if self.norm_layer is not None else [])
+
+    def build(self, input_shape):
+        self.layers = [EncoderLayer(embed_dim=self.embed_dim, num_heads=self.num_heads, ff_dim=self.ff_dim,
+                                    dense_kernel_initializer=self.dense_kernel_initializer,
+                                    attention_dropout_rate=self.attention_dropout_rate, dense_dropout_rate=self.dense_dropout_rate,
+                                    norm_epsilon=self.norm_epsilon, pre_norm=self.pre_norm) for _ in range(self.num_layers)]
+        for layer in self.layers:
+            layer.build(tuple(input_shape))
+            layer.built = True
+        if self.norm_layer is not None:
+            self.norm_layer.build(tuple(input_shape))
+            self.norm_layer.built = True
+
+    def call(self, inputs, mask=None, training=None, **kwargs):
+        x = inputs
+        for layer in self.layers:
+            x = layer(x, mask=mask, training=training)
+        if self.norm_output:
+            x = self.norm_layer(x)
+        return x
+
+    def get_config(self):
+        config = {"embed_dim": self.embed_dim, "num_heads": self.num_heads, "ff_dim": self.ff_dim, "num_layers": self.num_layers,
+                  "dense_kernel_initializer": self.dense_kernel_initializer, "attention_dropout_rate": self.attention_dropout_rate,
+                  "dense_dropout_rate": self.dense_dropout_rate, "norm_epsilon": self.norm_epsilon, "pre_norm": self.pre_norm,
+                  "norm_output": self.norm_output}
+        return dict(list(super(Encoder, self).get_config().items()) + list(config.items()))

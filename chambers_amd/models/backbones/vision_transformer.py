@@ -1,0 +1,227 @@
+"""chambers.models.backbones.vision_transformer on MI355X (reference:
+chambers/models/backbones/vision_transformer.py:103-292 generic builder, :403-652 zoo, :655 preprocess_input).
+
+`VisionTransformer(...)` returns a `Model` whose layers carry the reference's names, weight shapes and weight
+order (patch_embeddings/embedding, add_cls_token, pos_embedding, encoder[.layers[i], .norm_layer], feature,
+predictions — cf. test_units/manual_test_vit_weights.py:79-155), so timm / Keras weight mappings carry over via
+get_weights()/set_weights().  Execution goes through the whole-model HIP engine (chambers_amd/engine.py).
+
+Not built here ("next"): DistilledVisionTransformer / DeiT zoo entries and the pretrained-weight
+download (`weights="imagenet21k+_224"` needs network + .h5); `weights` may be None or a path to an .npz of
+Keras-named arrays."""
+import os
+
+import numpy as np
+import torch
+
+from ... import engine as E
+from ..._keras_like import Layer, Sequential
+from ...augmentations.image_augmentations import ImageNetNormalization
+from ... import initializers
+from ...layers.core import Conv2D, Dense, Dropout, Reshape
+from ...layers.embedding import ConcatEmbedding, LearnedEmbedding1D
+from ...layers.transformer import Encoder
+
+_PRETRAINED_TAGS = {"imagenet21k_224", "imagenet21k+_224", "imagenet21k+_384", "imagenet_224_deit", "imagenet_384_deit",
+                    "imagenet_224_deit_distilled", "imagenet_384_deit_distilled"}
+
+
+def _obtain_input_shape(input_tensor, input_shape, default_size, min_size):
+    """Static-shape validation of vision_transformer.py:117-146 (keras obtain_input_shape + full-shape check)."""
+    if input_tensor is not None:
+        input_shape = tuple(input_tensor.shape[1:])
+    if input_shape is None:
+        input_shape = (default_size, default_size, 3)
+    input_shape = tuple(input_shape)
+    if len(input_shape) != 3:
+        raise ValueError("`input_shape` must be a tuple of three integers.")
+    if None in input_shape:
+        raise ValueError("Input shape must be fully specified; got input shape {}.".format(input_shape))
+    if input_shape[-1] != 3:
+        raise ValueError("The input must have 3 channels; got `input_shape=" + str(input_shape) + "`")
+    if input_shape[0] < min_size or input_shape[1] < min_size:
+        raise ValueError("Input size must be at least " + str(min_size) + "x" + str(min_size) + "; got `input_shape=" + str(input_shape) + "`")
+    return input_shape
+
+
+class Model(Layer):
+    """The tf.keras.Model facade the reference's builder returns: named layers, weights, call/predict, plus
+    `train_step` (what `fit` + chambers.optimizers.AdamW would run)."""
+
+    def __init__(self, cfg, layers, name=None):
+        super().__init__(name=name)
+        self.cfg = cfg
+        self.layers = layers
+        self.built = True
+        self._engines = {}
+        self._loaded_version = {}
+
+    def _sublayers(self):
+        return list(self.layers)
+
+    def get_layer(self, name):
+        for layer in self.layers:
+            if layer.name == name:
+                return layer
+        raise ValueError("No such layer: " + name)
+
+    @property
+    def input_shape(self):
+        return (None,) + self.cfg.image_size + (3,)
+
+    # ---- Keras-named weight dictionary <-> layer variables
+    def keras_weights(self):
+        kw = {}
+        emb = self.get_layer("patch_embeddings").get_layer("embedding")
+        kw["patch_embeddings/embedding/kernel"], kw["patch_embeddings/embedding/bias"] = emb.kernel.numpy(), emb.bias.numpy()
+        kw["add_cls_token/embeddings"] = self.get_layer("add_cls_token").embedding.numpy()
+        kw["pos_embedding/embeddings"] = self.get_layer("pos_embedding").embedding.numpy()
+        enc = self.get_layer("encoder")
+        for i, l in enumerate(enc.layers):
+            p = "encoder/layer_%d/" % i
+            m = l.multi_head_attention
+            for nm in ("w_query", "b_query", "w_value", "b_value", "w_key", "b_key", "w_projection", "b_projection"):
+                kw[p + "multi_head_attention/" + nm] = getattr(m, nm).numpy()
+            kw[p + "norm1/gamma"], kw[p + "norm1/beta"] = l.norm1.gamma.numpy(), l.norm1.beta.numpy()
+            kw[p + "dense1/kernel"], kw[p + "dense1/bias"] = l.dense1.kernel.numpy(), l.dense1.bias.numpy()
+            kw[p + "dense2/kernel"], kw[p + "dense2/bias"] = l.dense2.kernel.numpy(), l.dense2.bias.numpy()
+            kw[p + "norm2/gamma"], kw[p + "norm2/beta"] = l.norm2.gamma.numpy(), l.norm2.beta.numpy()
+        kw["encoder/norm/gamma"], kw["encoder/norm/beta"] = enc.norm_layer.gamma.numpy(), enc.norm_layer.beta.numpy()
+        for nm in ("feature", "predictions"):
+            try:
+                l = self.get_layer(nm)
+                kw[nm + "/kernel"], kw[nm + "/bias"] = l.kernel.numpy(), l.bias.numpy()
+            except ValueError:
+                pass
+        return kw
+
+    def assign_keras_weights(self, kw):
+        emb = self.get_layer("patch_embeddings").get_layer("embedding")
+        emb.kernel.assign(kw["patch_embeddings/embedding/kernel"]); emb.bias.assign(kw["patch_embeddings/embedding/bias"])
+        self.get_layer("add_cls_token").embedding.assign(kw["add_cls_token/embeddings"])
+        self.get_layer("pos_embedding").embedding.assign(kw["pos_embedding/embeddings"])
+        enc = self.get_layer("encoder")
+        for i, l in enumerate(enc.layers):
+            p = "encoder/layer_%d/" % i
+            m = l.multi_head_attention
+            for nm in ("w_query", "b_query", "w_value", "b_value", "w_key", "b_key", "w_projection", "b_projection"):
+                getattr(m, nm).assign(kw[p + "multi_head_attention/" + nm])
+            l.norm1.gamma.assign(kw[p + "norm1/gamma"]); l.norm1.beta.assign(kw[p + "norm1/beta"])
+            l.dense1.kernel.assign(kw[p + "dense1/kernel"]); l.dense1.bias.assign(kw[p + "dense1/bias"])
+            l.dense2.kernel.assign(kw[p + "dense2/kernel"]); l.dense2.bias.assign(kw[p + "dense2/bias"])
+            l.norm2.gamma.assign(kw[p + "norm2/gamma"]); l.norm2.beta.assign(kw[p + "norm2/beta"])
+        enc.norm_layer.gamma.assign(kw["encoder/norm/gamma"]); enc.norm_layer.beta.assign(kw["encoder/norm/beta"])
+        for nm in ("feature", "predictions"):
+            if nm + "/kernel" in kw:
+                l = self.get_layer(nm)
+                l.kernel.assign(kw[nm + "/kernel"]); l.bias.assign(kw[nm + "/bias"])
+        self._bump()
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.assign_keras_weights({k: z[k] for k in z.files})
+
+    def save_weights(self, path):
+        np.savez(path, **self.keras_weights())
+
+    # ---- execution
+    def engine(self, batch_size, training=False, **kw):
+        key = (int(batch_size), bool(training))
+        if key not in self._engines:
+            self._engines[key] = E.ViTEngine(self.cfg, batch_size, training=training, **kw)
+            self._loaded_version[key] = -1
+        eng = self._engines[key]
+        if self._loaded_version[key] != self._version:
+            eng.load_keras_weights(self.keras_weights())
+            self._loaded_version[key] = self._version
+        return eng
+
+    def call(self, inputs, training=None, **kwargs):
+        """inputs: float32 NHWC already preprocessed (the reference model's own input), or uint8 NHWC, in which case
+        `preprocess_input` (ImageNetNormalization 'tf') is fused in front.  Returns float32 logits / features."""
+        eng = self.engine(inputs.shape[0], training=False)
+        if inputs.dtype != torch.uint8:
+            from ... import kernels as K
+            K.patchify_f32(inputs.to(torch.float32), self.cfg.patch_size, out=eng.patches)
+            return eng.forward(None, training=bool(training), prepatched=True).clone()
+        return eng.forward(inputs, training=bool(training)).clone()
+
+    predict = call
+
+    def train_step(self, images_u8, labels, **opt):
+        eng = self.engine(images_u8.shape[0], training=True)
+        loss = eng.train_step(images_u8, labels, **opt)
+        return loss
+
+    def sync_from_engine(self, batch_size):
+        """Copy trained weights back into the layer variables (Keras layout)."""
+        eng = self._engines[(int(batch_size), True)]
+        self.assign_keras_weights(eng.export_keras_weights())
+        self._loaded_version[(int(batch_size), True)] = self._version
+
+
+def VisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate=0.1, input_tensor=None, input_shape=None,
+                      include_top=True, weights="imagenet21k+_224", pooling="cls", feature_dim=None, classes=1000,
+                      classifier_activation=None, model_name=None):
+    if weights in _PRETRAINED_TAGS:
+        if feature_dim is not None:
+            raise ValueError("'weights' and 'feature_dim' are mutually exclusive.")
+        raise RuntimeError("pretrained weights %r are downloaded from GitHub releases by the reference (vision_transformer.py:149-167); "
+                           "this build has no network path — pass weights=None or a path to an .npz of Keras-named arrays" % (weights,))
+    if classifier_activation not in (None, "linear"):
+        raise ValueError("classifier_activation other than None is not on the hot path (logits feed the fused softmax-CE)")
+    shape = _obtain_input_shape(input_tensor, input_shape, default_size=224, min_size=patch_size)
+    cfg = E.ViTConfig(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate, image_size=shape[:2], classes=classes,
+                      include_top=include_top, feature_dim=feature_dim, pooling=pooling or "cls")
+    tn = initializers.TruncatedNormal(stddev=0.02)
+    patch_embeddings = Sequential([Conv2D(filters=patch_dim, kernel_size=patch_size, strides=patch_size, padding="valid", name="embedding"),
+                                   Reshape([-1, patch_dim])], name="patch_embeddings")
+    add_cls = ConcatEmbedding(n_embeddings=1, embedding_dim=patch_dim, side="left", axis=1, initializer=tn, name="add_cls_token")
+    pos = LearnedEmbedding1D(initializer=tn, name="pos_embedding")
+    drop = Dropout(dropout_rate)
+    encoder = Encoder(embed_dim=patch_dim, num_heads=n_heads, ff_dim=ff_dim, num_layers=n_encoder_layers, attention_dropout_rate=dropout_rate,
+                      dense_dropout_rate=dropout_rate, pre_norm=True, norm_output=True, name="encoder")
+    n_tok = cfg.n_tokens
+    for l in patch_embeddings.layers[:1]:
+        l.build((None,) + shape); l.built = True
+    add_cls.build((None, cfg.n_patches, patch_dim)); add_cls.built = True
+    pos.build((None, n_tok, patch_dim)); pos.built = True
+    encoder.build((None, n_tok, patch_dim)); encoder.built = True
+    layers = [patch_embeddings, add_cls, pos, drop, encoder]
+    feat_in = patch_dim
+    if feature_dim is not None:
+        f = Dense(units=feature_dim, activation="tanh", name="feature")
+        f.build((None, patch_dim)); f.built = True
+        layers.append(f)
+        feat_in = feature_dim
+    if include_top:
+        head = Dense(units=classes, activation=classifier_activation, name="predictions")
+        head.build((None, feat_in)); head.built = True
+        layers.append(head)
+    model = Model(cfg, layers, name=model_name)
+    if weights is not None:
+        if not os.path.exists(str(weights)):
+            raise ValueError("weights file not found: %s" % (weights,))
+        model.load_weights(weights)
+    return model
+
+
+def _zoo(model_name, patch_size, patch_dim, n_layers, n_heads, ff_dim, default_weights):
+    def build(input_tensor=None, input_shape=None, include_top=True, weights=default_weights, pooling="cls", feature_dim=None, classes=1000,
+              classifier_activation=None):
+        return VisionTransformer(patch_size=patch_size, patch_dim=patch_dim, n_encoder_layers=n_layers, n_heads=n_heads, ff_dim=ff_dim,
+                                 dropout_rate=0.1, feature_dim=feature_dim, input_tensor=input_tensor, input_shape=input_shape,
+                                 include_top=include_top, weights=weights, pooling=pooling, classes=classes,
+                                 classifier_activation=classifier_activation, model_name=model_name)
+    build.__name__ = model_name
+    return build
+
+
+# reference zoo constants: vision_transformer.py:403-652
+ViTS16 = _zoo("vits16", 16, 384, 12, 6, 1536, "imagenet_224_deit")
+ViTB16 = _zoo("vitb16", 16, 768, 12, 12, 3072, "imagenet21k+_224")
+ViTB32 = _zoo("vitb32", 32, 768, 12, 12, 3072, "imagenet21k+_384")
+ViTL16 = _zoo("vitl16", 16, 1024, 24, 16, 4096, "imagenet21k+_224")
+ViTL32 = _zoo("vitl32", 32, 1024, 24, 16, 4096, "imagenet21k+_384")
+
+preprocess_input = ImageNetNormalization(mode="tf", name="vit_preprocess")   # vision_transformer.py:655

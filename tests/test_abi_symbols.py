@@ -1,0 +1,70 @@
+"""CPU tier: the C-ABI shared library loads without a GPU and exports every symbol include/chambers_hip.h declares
+(no compute call is made here); the product path refuses to run without it / without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "chambers_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(chb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared()
+    assert len(names) >= 25
+    for must in ("chb_aug_pointwise", "chb_aug_affine", "chb_aug_equalize", "chb_gemm_nt", "chb_gemm_tn", "chb_attention_fwd",
+                 "chb_attention_bwd", "chb_layernorm_fwd", "chb_adamw", "chb_normalize_u8"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from chambers_amd import _lib
+    lib = ctypes.CDLL(_lib.lib_path())
+    for name in _declared():
+        assert hasattr(lib, name), "libchambers_hip.so lacks %s" % name
+    typed = _lib.load()
+    assert typed.chb_version() == 1 and typed.chb_build_arch() == b"gfx950"
+    # every declared entry has a ctypes prototype (and vice versa)
+    assert set(_declared()) == set(_lib.PROTOTYPES) | set(_lib.INFO_SYMBOLS)
+
+
+def test_every_entry_cites_the_reference():
+    text = open(os.path.join(ROOT, "include", "chambers_hip.h")).read()
+    assert text.count(".py:") >= 15          # file:line citations of the reference interface each entry replaces
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_path_fails_loudly_without_gpu():
+    from chambers_amd import _lib, augmentations as aug
+    from chambers_amd.engine import ViTConfig, ViTEngine
+    x = torch.zeros((1, 8, 8, 3), dtype=torch.uint8)
+    with pytest.raises(_lib.ChambersHipError):
+        aug.Invert()(x)
+    with pytest.raises(RuntimeError):
+        ViTEngine(ViTConfig(16, 128, 1, 2, 256, image_size=(32, 32)), 1)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    from chambers_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "lib_path", lambda: "/nonexistent/libchambers_hip.so")
+    with pytest.raises(_lib.ChambersHipError):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for root, _d, files in os.walk(os.path.join(ROOT, "chambers_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(f)
+    assert not bad, bad

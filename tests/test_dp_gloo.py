@@ -1,0 +1,83 @@
+"""CPU tier, world_size 2 over gloo: the data-parallel gradient exchange of the engine (GradBucketReducer) — bucketed,
+asynchronous all-reduce of contiguous slices of the flat gradient buffer, averaging folded into grad_scale — and the
+sharding arithmetic bench.py relies on (weak scaling: every rank holds its own batch, parameters replicated)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chambers_amd.engine import GradBucketReducer, ViTConfig, build_param_table
+    cfg = ViTConfig(16, 128, 2, 2, 256, image_size=(32, 32), classes=10)
+    specs, total, buckets = build_param_table(cfg)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(total, generator=g)
+    local = flat.clone()
+    red = GradBucketReducer(flat, buckets)
+    assert red.active and red.world == world and abs(red.grad_scale - 1.0 / world) < 1e-12
+    # backward marks buckets final in order 0..L+1; collectives are asynchronous until finish()
+    for k in range(len(buckets)):
+        red.bucket_ready(k)
+    assert len(red.handles) == len(buckets)
+    red.finish()
+    assert red.handles == []
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expect = sum(gathered)
+    assert torch.allclose(flat, expect, atol=1e-6)
+    # parameters stay bit-identical across ranks when every rank applies the same averaged gradient
+    p = torch.ones(total)
+    p -= 0.1 * flat * red.grad_scale
+    ps = [torch.empty_like(p) for _ in range(world)]
+    dist.all_gather(ps, p)
+    assert torch.equal(ps[0], ps[1])
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a = np.load(tmp_path / "rank0.npy")
+    b = np.load(tmp_path / "rank1.npy")
+    np.testing.assert_array_equal(a, b)
+
+
+def test_reducer_is_a_noop_single_process():
+    from chambers_amd.engine import GradBucketReducer
+    flat = torch.arange(10.0)
+    red = GradBucketReducer(flat, [(0, 4), (4, 10)])
+    assert not red.active and red.grad_scale == 1.0
+    red.bucket_ready(0)
+    red.bucket_ready(1)
+    red.finish()
+    assert torch.equal(flat, torch.arange(10.0))
+
+
+def test_buckets_cover_the_flat_buffer_in_backward_order():
+    from chambers_amd.engine import ViTConfig, build_param_table
+    cfg = ViTConfig(16, 768, 12, 12, 3072)
+    specs, total, buckets = build_param_table(cfg)
+    assert buckets[0][0] == 0 and buckets[-1][1] == total
+    names = [s.name for s in specs]
+    assert names[0].startswith("predictions") and names[-1] == "patch_embeddings/embedding/bias"
+    first_block = [n for n in names if n.startswith("encoder/layer_")][0]
+    assert first_block.startswith("encoder/layer_11/")          # last block's gradients are final first
+    sizes_mb = [(hi - lo) * 4 / 2 ** 20 for lo, hi in buckets]
+    assert 25 < sizes_mb[1] < 30                                 # one ViT-B block = 7.09 M params = 27 MiB fp32 per bucket

@@ -1,0 +1,140 @@
+"""CPU tier: host-side mirror of the reference interface — constructor arguments, get_config() keys, serialisation
+round trips, weight naming/order, magnitude maps, policy table, parameter table and weight-layout conversion."""
+import numpy as np
+import pytest
+
+from oracle import augment_ref as A
+from oracle import rng_ref
+
+
+def test_randaugment_op_table_and_kwargs_match_reference_text():
+    from chambers_amd.augmentations import augmentation_schemes as S
+    ra = S.RandAugment(2, 9)
+    names = [type(t).__name__ for t in ra.transforms]
+    assert names == A.RANDAUGMENT_OPS                                   # augmentation_schemes.py:181-198
+    assert S._AUTO_AUGMENT_POLICY_V0 == A.AUTO_AUGMENT_POLICY_V0        # :12-39
+    by = dict(zip(names, ra.transforms))
+    assert abs(by["Brightness"].factor - 1.72) < 1e-12 and abs(by["ShearX"].level - 0.27) < 1e-12
+    assert by["TranslateX"].pixels == 90 and by["Posterize"].bits == 3 and by["Solarize"].threshold == 230
+    assert by["SolarizeAdd"].addition == 99 and by["CutOut"].mask_size == 72 and by["CutOut"].constant_values == 128
+    assert abs(by["Rotate"].degrees - 27.0) < 1e-12 and by["Rotate"].fill_value == 128 and by["ShearY"].interpolation == "nearest"
+    for name in names:
+        assert S._get_transform(name, 4) is not None
+
+
+def test_get_config_keys_match_reference():
+    from chambers_amd import augmentations as aug
+    base = {"name", "trainable", "dtype"}
+    warp = {"interpolation", "fill_mode", "fill_value"}
+    assert set(aug.RandAugment(2, 9).get_config()) == base | {"n_transforms", "magnitude", "elementwise"}
+    assert set(aug.AutoAugment().get_config()) == base | {"elementwise"}
+    assert set(aug.Rotate(3.0).get_config()) == base | warp | {"degrees"}
+    assert set(aug.ShearX(0.1).get_config()) == base | warp | {"level"}
+    assert set(aug.TranslateY(3).get_config()) == base | warp | {"pixels"}
+    assert set(aug.Posterize(3).get_config()) == base | {"bits"}
+    assert set(aug.SolarizeAdd(1, 2).get_config()) == base | {"addition", "threshold"}
+    assert set(aug.CutOut(8).get_config()) == base | {"mask_size", "constant_values"}
+    assert set(aug.ImageNetNormalization("tf").get_config()) == base | {"mode"}
+    for cls in (aug.Color, aug.Contrast, aug.Brightness, aug.Sharpness):
+        assert set(cls(0.5).get_config()) == base | {"factor"}
+    rc = aug.RandomChance(aug.Invert(), 0.3)
+    assert rc.name == "random_chance_invert" or rc.name.startswith("random_chance_invert")
+    cfg = rc.get_config()
+    assert set(cfg) == base | {"transform", "probability"} and cfg["transform"]["class_name"] == "Chambers>Invert"
+    rc2 = aug.RandomChance.from_config(cfg)
+    assert isinstance(rc2.transform, aug.Invert) and rc2.probability == 0.3
+    ch = aug.RandomChoice([aug.Invert(), aug.Posterize(2)], n_transforms=2)
+    ch2 = aug.RandomChoice.from_config(ch.get_config())
+    assert [type(t).__name__ for t in ch2.transforms] == ["Invert", "Posterize"] and ch2.n_transforms == 2
+    assert ch.compute_output_shape((4, 8, 8, 3)) == [4, 8, 8, 3]
+
+
+def test_layer_configs_and_weight_order():
+    from chambers_amd.layers.attention import MultiHeadAttention
+    from chambers_amd.layers.transformer import Encoder, EncoderLayer
+    base = {"name", "trainable", "dtype"}
+    mha = MultiHeadAttention(head_dim=64, num_heads=2)
+    assert set(mha.get_config()) == base | {"head_dim", "num_heads", "dense_kernel_initializer", "dropout_rate", "causal"}
+    mha.build([(None, 5, 128)] * 3)
+    assert [w.name.split("/")[-1] for w in mha.weights] == ["w_query:0", "b_query:0", "w_value:0", "b_value:0", "w_key:0", "b_key:0",
+                                                            "w_projection:0", "b_projection:0"]      # layers/attention.py:54-96
+    assert [w.shape for w in mha.weights] == [(128, 2, 64), (2, 1, 64)] * 3 + [(2, 128, 64), (1, 128)]
+    el = EncoderLayer(embed_dim=128, num_heads=2, ff_dim=256, pre_norm=True)
+    assert set(el.get_config()) == base | {"embed_dim", "num_heads", "ff_dim", "dense_kernel_initializer", "attention_dropout_rate",
+                                           "dense_dropout_rate", "norm_epsilon", "pre_norm"}
+    enc = Encoder(128, 2, 256, 3, pre_norm=True, norm_output=True)
+    assert set(enc.get_config()) == base | {"embed_dim", "num_heads", "ff_dim", "num_layers", "dense_kernel_initializer",
+                                            "attention_dropout_rate", "dense_dropout_rate", "norm_epsilon", "pre_norm", "norm_output"}
+    enc.build((None, 5, 128))
+    assert len(enc.layers) == 3 and len(enc.weights) == 3 * 16 + 2
+    with pytest.raises(ValueError):
+        mha.set_weights([np.zeros((1,))])
+
+
+def test_model_builder_signature_names_and_errors():
+    from chambers_amd.models.backbones import vision_transformer as V
+    from chambers_amd.models import vit
+    assert vit.ViTB16 is V.ViTB16 and V.preprocess_input.mode == "tf" and V.preprocess_input.name == "vit_preprocess"
+    m = V.VisionTransformer(16, 128, 2, 2, 256, input_shape=(64, 48, 3), weights=None, classes=10, model_name="tiny")
+    assert m.name == "tiny"
+    names = [l.name for l in m.layers]
+    assert names[:3] == ["patch_embeddings", "add_cls_token", "pos_embedding"] and names[3].startswith("dropout") and names[4:] == ["encoder", "predictions"]
+    assert m.get_layer("patch_embeddings").get_layer("embedding").kernel.shape == (16, 16, 3, 128)
+    assert m.get_layer("add_cls_token").embedding.shape == (1, 128) and m.get_layer("pos_embedding").embedding.shape == (13, 128)
+    assert m.get_layer("encoder").norm_layer is not None and len(m.get_layer("encoder").layers) == 2
+    n_params = 16 * 16 * 3 * 128 + 128 + 128 + 13 * 128 + 2 * (4 * (128 * 128 + 128) + 2 * 128 * 256 + 256 + 128 + 4 * 128) + 2 * 128 + 128 * 10 + 10
+    assert m.count_params() == n_params
+    w = m.get_weights()
+    m.set_weights(w)
+    with pytest.raises(ValueError):
+        V.VisionTransformer(16, 128, 2, 2, 256, input_shape=(8, 8, 3), weights=None)            # smaller than a patch
+    with pytest.raises(ValueError):
+        V.VisionTransformer(16, 128, 2, 2, 256, input_shape=(64, None, 3), weights=None)         # not fully specified
+    with pytest.raises(ValueError):
+        V.VisionTransformer(16, 128, 2, 2, 256, weights="imagenet21k+_224", feature_dim=8)       # mutually exclusive
+    # ViT-B/16 parameter count of the reference zoo config (86,567,656 - SURVEY §5)
+    from chambers_amd.engine import ViTConfig, build_param_table
+    specs, _tot, buckets = build_param_table(ViTConfig(16, 768, 12, 12, 3072))
+    real = sum(s.size for s in specs) - (1024 - 1000) * (768 + 1)
+    assert real == 86567656
+    assert len(buckets) == 14 and buckets[0][0] == 0 and all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
+
+
+def test_adamw_facade_regex_semantics():
+    from chambers_amd.optimizers import AdamW
+    with pytest.raises(ValueError):
+        AdamW(0.1, decay_include=["a"], decay_exclude=["b"])
+    o = AdamW(0.05, decay_exclude=["bias", "norm", "embeddings"])
+    assert o._is_decay_allowed("encoder/layer_0/dense1/kernel") and not o._is_decay_allowed("encoder/layer_0/dense1/bias")
+    assert not o._is_decay_allowed("pos_embedding/embeddings") and not o._is_decay_allowed("encoder/norm/gamma")
+    o2 = AdamW(0.05, decay_include=["kernel$"])
+    assert o2._is_decay_allowed("predictions/kernel") and not o2._is_decay_allowed("predictions/bias")
+    assert set(o.get_config()) >= {"weight_decay", "decay_include", "decay_exclude", "learning_rate", "beta_1", "beta_2", "epsilon", "amsgrad"}
+    from chambers_amd.engine import ViTConfig, build_param_table
+    specs, _, _ = build_param_table(ViTConfig(16, 128, 1, 2, 256, image_size=(32, 32), classes=10), o.decay_fn())
+    assert {s.name: s.decay for s in specs}["encoder/layer_0/qkv/kernel"] and not {s.name: s.decay for s in specs}["encoder/layer_0/qkv/bias"]
+
+
+def test_rng_contract_matches_oracle_definition():
+    from chambers_amd import rng
+    for seed, step, site in ((0, 0, 0), (7, 3, 11), (2 ** 40 + 5, 1000, 36)):
+        assert rng.site_key(seed, step, site) == rng_ref.site_key(seed, step, site)
+    keys = {rng.site_key(1, s, k) for s in range(50) for k in range(40)}
+    assert len(keys) == 2000
+    m = rng_ref.keep_mask(1 << 20, 12345, 0.1)
+    assert abs(m.mean() - 0.9) < 2e-3
+    assert rng.site_attn(2) == 7 and rng.site_proj(2) == 8 and rng.site_mlp(2) == 9 and rng.SITE_EMBED == 0
+
+
+def test_contrast_constant_host_side():
+    from chambers_amd.augmentations import Contrast
+    for n in (16, 224 * 224, 2 * 224 * 224, 384 * 384, 65279, 65280, 65535, 65536):
+        assert Contrast.degenerate_constant(n) == A.contrast_constant(n)
+
+
+def test_rotate_transform_host_side_matches_oracle():
+    from chambers_amd.augmentations import Rotate
+    import math
+    for deg, neg, h, w in ((27.0, False, 224, 224), (27.0, True, 37, 53), (0.0, False, 5, 9), (90.0, True, 64, 48)):
+        rad = deg * math.pi / 180.0
+        np.testing.assert_array_equal(Rotate.transform_for(-rad if neg else rad, h, w), A.rotate_transform(deg, neg, h, w))
