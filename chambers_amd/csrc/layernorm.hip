@@ -66,8 +66,9 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, float* __restrict__ dx, int64_t dx_stride,
                                                      int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                     int D) {
-    __shared__ float red[2][4][NCH * 256];
+                                                     int D, bf16_t* __restrict__ dz, float* __restrict__ dzsum, float drop_scale,
+                                                     uint32_t drop_thr, uint32_t drop_key) {
+    __shared__ float red[3][4][NCH * 256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nchunk = D >> 2;
     const float inv_d = 1.0f / (float)D;
@@ -79,6 +80,9 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
         dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float4 dzs[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) dzs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * x_stride);
         const uint2* dyr = reinterpret_cast<const uint2*>(dy + (int64_t)row * D);
@@ -117,6 +121,26 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 dxr[c] = o;
+                if (dz) {
+                    // backward of the keras Dropout that follows in the backward chain: dz = dx * keep / (1-rate), bf16 GEMM
+                    // operand; its column sums are the bias gradient of that GEMM's layer
+                    float4 z = o;
+                    if (drop_thr) {
+                        const uint64_t e = (uint64_t)row * (uint64_t)D + (uint64_t)(c * 4);
+                        bool k0, k1, k2, k3;
+                        chb_keep2((uint32_t)(e >> 1), drop_key, drop_thr, k0, k1);
+                        chb_keep2((uint32_t)(e >> 1) + 1u, drop_key, drop_thr, k2, k3);
+                        z.x = k0 ? z.x * drop_scale : 0.f; z.y = k1 ? z.y * drop_scale : 0.f;
+                        z.z = k2 ? z.z * drop_scale : 0.f; z.w = k3 ? z.w * drop_scale : 0.f;
+                    }
+                    uint2 zb;
+                    zb.x = pack_bf16x2(z.x, z.y);
+                    zb.y = pack_bf16x2(z.z, z.w);
+                    reinterpret_cast<uint2*>(dz + (int64_t)row * D)[c] = zb;
+                    // sum what the GEMM will read (the bf16-rounded values), as the separate colsum pass did
+                    dzs[j].x += bf16_to_f32((bf16_t)(zb.x & 0xffff)); dzs[j].y += bf16_to_f32((bf16_t)(zb.x >> 16));
+                    dzs[j].z += bf16_to_f32((bf16_t)(zb.y & 0xffff)); dzs[j].w += bf16_to_f32((bf16_t)(zb.y >> 16));
+                }
             }
         }
     }
@@ -128,6 +152,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
         red[0][wave][base + 2] = dg[j].z; red[0][wave][base + 3] = dg[j].w;
         red[1][wave][base + 0] = db[j].x; red[1][wave][base + 1] = db[j].y;
         red[1][wave][base + 2] = db[j].z; red[1][wave][base + 3] = db[j].w;
+        red[2][wave][base + 0] = dzs[j].x; red[2][wave][base + 1] = dzs[j].y;
+        red[2][wave][base + 2] = dzs[j].z; red[2][wave][base + 3] = dzs[j].w;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
@@ -135,6 +161,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
         const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
         atomicAdd(dgamma + c, g);
         atomicAdd(dbeta + c, b);
+        if (dzsum) atomicAdd(dzsum + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
     }
 }
 
@@ -168,8 +195,13 @@ int chb_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, cons
 }
 
 int chb_layernorm_bwd(const void* dy, const float* x, int64_t x_stride, const float* mean, const float* rstd, const float* gamma,
-                      float* dx, int64_t dx_stride, int accumulate, float* dgamma, float* dbeta, int M, int D, void* stream) {
+                      float* dx, int64_t dx_stride, int accumulate, float* dgamma, float* dbeta, int M, int D, void* dz_bf16,
+                      float* dz_colsum, float drop_rate, uint32_t drop_key, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || M < 0 || D <= 0) return CHB_EINVAL;
+    if (drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
+    bf16_t* dz = (bf16_t*)dz_bf16;
+    const float dscale = 1.0f / (1.0f - drop_rate);
+    const uint32_t dthr = drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u;
     if ((D & 3) || D > 1024 || (x_stride & 3) || (dx_stride & 3)) return CHB_EUNSUPPORTED;
     if (M == 0) return CHB_OK;
     const int nch = (D / 4 + 63) / 64;
@@ -179,10 +211,10 @@ int chb_layernorm_bwd(const void* dy, const float* x, int64_t x_stride, const fl
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* d = (const bf16_t*)dy;
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D); break;
-        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D); break;
-        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D); break;
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key); break;
+        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key); break;
     }
     CHB_LAUNCH_CHECK();
     return CHB_OK;

@@ -460,31 +460,37 @@ class ViTEngine:
         K.layernorm_bwd(self.dhf, self.x_final, n * d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, n * d, False,
                         self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
         self.reducer.bucket_ready(0)
+        # dz of the last block's MLP branch (afterwards every LayerNorm backward emits the next dz + its bias gradient)
+        K.dropout_bwd(self.dx, self.dz, M, d, rate, key(rng.site_mlp(L - 1)))
+        K.colsum(self.dz, self.g("encoder/layer_%d/dense2/bias" % (L - 1)), m=M)
         for l in reversed(range(L)):
             a = self.acts[l]
             pre = "encoder/layer_%d/" % l
-            # MLP branch
-            K.dropout_bwd(self.dx, self.dz, M, d, rate, key(rng.site_mlp(l)))
+            # MLP branch (self.dz = dropout-backward of dx at site_mlp(l))
             K.gemm_tn(a["u"], self.dz, self.g(pre + "dense2/kernel"), m=Mp)
-            K.colsum(self.dz, self.g(pre + "dense2/bias"), m=M)
             K.gemm_nt(self.dz, self.wb(pre + "dense2/kernel"), self.da1, m=M, epilogue=K.EPI_DGELU, aux=a["a1"])
             K.gemm_tn(a["h2"], self.da1, self.g(pre + "dense1/kernel"), m=Mp)
             K.colsum(self.da1, self.g(pre + "dense1/bias"), m=M)
             K.gemm_nt(self.da1, self.wb(pre + "dense1/kernel"), self.dh, m=M)
             K.layernorm_bwd(self.dh, a["xmid"], d, a["mean2"], a["rstd2"], self.p(pre + "norm2/gamma"), self.dx, d, True,
-                            self.g(pre + "norm2/gamma"), self.g(pre + "norm2/beta"), M, d)
-            # attention branch
-            K.dropout_bwd(self.dx, self.dz, M, d, rate, key(rng.site_proj(l)))
+                            self.g(pre + "norm2/gamma"), self.g(pre + "norm2/beta"), M, d, dz=self.dz,
+                            dz_colsum=self.g(pre + "proj/bias"), drop_rate=rate, drop_key=key(rng.site_proj(l)))
+            # attention branch (self.dz = dropout-backward of dx at site_proj(l))
             K.gemm_tn(a["o"], self.dz, self.g(pre + "proj/kernel"), m=Mp)
-            K.colsum(self.dz, self.g(pre + "proj/bias"), m=M)
             K.gemm_nt(self.dz, self.wb(pre + "proj/kernel"), self.do, m=M)
             K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], self.dqkv, self.B, n, cfg.n_heads, cfg.head_dim, rate,
                             key(rng.site_attn(l)))
             K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp)
             K.colsum(self.dqkv, self.g(pre + "qkv/bias"), m=M)
             K.gemm_nt(self.dqkv, self.wb(pre + "qkv/kernel"), self.dh, m=M)
-            K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
-                            self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d)
+            if l > 0:
+                K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
+                                self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d, dz=self.dz,
+                                dz_colsum=self.g("encoder/layer_%d/dense2/bias" % (l - 1)), drop_rate=rate,
+                                drop_key=key(rng.site_mlp(l - 1)))
+            else:
+                K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
+                                self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d)
             self.reducer.bucket_ready(L - l)
         # embedding stage
         K.embed_bwd(self.dx, self.dpatch, self.g("pos_embedding/embeddings"), self.g("add_cls_token/embeddings"), self.B, n, d, rate,

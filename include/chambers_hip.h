@@ -123,10 +123,13 @@ int chb_gemm_tn(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* 
  * stride x_stride, y bf16 [M,D]; mean/rstd fp32 [M] saved for backward. D % 4 == 0, D <= 1024. */
 int chb_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* y_bf16,
                       float* mean, float* rstd, int M, int D, float eps, void* stream);
-/* dx[row] (+)= LN'(dy); dgamma/dbeta fp32 [D] accumulated with atomics (caller zeroes). */
+/* dx[row] (+)= LN'(dy); dgamma/dbeta fp32 [D] accumulated with atomics (caller zeroes).
+ * Optional fused tail (dz_bf16 != NULL): the backward of the keras Dropout that precedes this residual sum in
+ * forward order (layers/transformer.py:69,76) — dz[M,D] = bf16(dx * keep / (1-rate)) (dx_stride must be D), the
+ * operand of the next dgrad/wgrad GEMMs, and dz_colsum[D] += its column sums (that layer's bias gradient). */
 int chb_layernorm_bwd(const void* dy_bf16, const float* x, int64_t x_stride, const float* mean, const float* rstd,
                       const float* gamma, float* dx, int64_t dx_stride, int accumulate, float* dgamma, float* dbeta,
-                      int M, int D, void* stream);
+                      int M, int D, void* dz_bf16, float* dz_colsum, float drop_rate, uint32_t drop_key, void* stream);
 
 /* MultiHeadAttention core (layers/attention.py:7-23,113-125): softmax(QK^T/sqrt(hd)) with
  * dropout on the probabilities, times V.  qkv bf16 [B*N, 3*H*hd] = [Q heads | K heads | V heads];

@@ -206,6 +206,31 @@ def test_layernorm_fwd_bwd(m, d):
     assert rel_l2(dx2.cpu(), xd.grad) < 1e-5
 
 
+def test_layernorm_bwd_fused_dropout_tail():
+    from chambers_amd import kernels as K
+    m, d, rate, key = 300, 192, 0.1, 31337
+    x = torch.randn(m, d, generator=g(36))
+    gamma = torch.randn(d, generator=g(37))
+    dy = bf(torch.randn(m, d, generator=g(38)))
+    mean = x.mean(-1).cuda()
+    rstd = (1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-6)).cuda()
+    dx0 = torch.randn(m, d, generator=g(39))
+    dxa, dxb = dx0.cuda().clone(), dx0.cuda().clone()
+    dg1, db1, dg2, db2 = (torch.zeros(d, device="cuda") for _ in range(4))
+    K.layernorm_bwd(dy.cuda(), x.cuda(), d, mean, rstd, gamma.cuda(), dxa, d, True, dg1, db1, m, d)
+    dz = torch.zeros(m, d, dtype=torch.bfloat16, device="cuda")
+    zsum = torch.zeros(d, device="cuda")
+    K.layernorm_bwd(dy.cuda(), x.cuda(), d, mean, rstd, gamma.cuda(), dxb, d, True, dg2, db2, m, d, dz=dz, dz_colsum=zsum, drop_rate=rate,
+                    drop_key=key)
+    assert torch.equal(dxa, dxb) and rel_l2(dg1.cpu(), dg2.cpu()) < 1e-5 and rel_l2(db1.cpu(), db2.cpu()) < 1e-5   # atomics: order-dependent last bits
+    ref = torch.empty(m, d, dtype=torch.bfloat16, device="cuda")
+    K.dropout_bwd(dxa, ref, m, d, rate, key)
+    assert torch.equal(dz, ref)
+    cs = torch.zeros(d, device="cuda")
+    K.colsum(ref, cs)
+    assert rel_l2(zsum.cpu(), cs.cpu()) < 1e-5
+
+
 def test_layernorm_strided_rows():
     from chambers_amd import kernels as K
     bsz, n, d = 4, 5, 192
