@@ -129,6 +129,12 @@ __global__ void __launch_bounds__(256) pointwise_kernel(const uint8_t* __restric
     }
 }
 
+inline int row_grid(int64_t rows) {   // one wave per image row, 4 rows per block
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
 inline int stream_grid(int64_t n_groups) {
     int64_t blocks = (n_groups + 255) / 256;
     if (blocks > 8192) blocks = 8192;  // 256 CUs x 8 blocks x 4: grid-stride the rest
@@ -137,90 +143,106 @@ inline int stream_grid(int64_t n_groups) {
 }
 
 // ---- nearest-neighbour projective warp (tfa.image.transform), :333-341 etc. -----
+// One wave per output row (no per-thread integer division), a lane owns 4 output pixels; each source pixel is
+// fetched with ONE unaligned dword load (3 payload bytes) instead of three byte loads.
+struct __attribute__((packed)) u32_unaligned { uint32_t v; };
+
 __global__ void __launch_bounds__(256) affine_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
                                                      int W, int C, const float* __restrict__ tdev, int per_image,
                                                      float t0, float t1, float t2, float t3, float t4, float t5,
                                                      float t6, float t7, int fill) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wq = (W + 3) >> 2;  // x-quads per row
-    const int64_t total = (int64_t)B * H * wq;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
-        const int xq = (int)(q % wq);
-        const int64_t r = q / wq;
-        const int oy = (int)(r % H);
-        const int n = (int)(r / H);
+    const int rows = B * H;
+    const int64_t total_bytes = (int64_t)B * H * W * C;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int n = row / H, oy = row - n * H;
         float a0 = t0, a1 = t1, a2 = t2, b0 = t3, b1 = t4, b2 = t5, c0 = t6, c1 = t7;
         if (tdev) {
             const float* t = tdev + (per_image ? (int64_t)n * 8 : 0);
             a0 = t[0]; a1 = t[1]; a2 = t[2]; b0 = t[3]; b1 = t[4]; b2 = t[5]; c0 = t[6]; c1 = t[7];
         }
-        const uint8_t* img = in + (int64_t)n * H * W * C;
-        uint8_t* orow = out + ((int64_t)n * H + oy) * (int64_t)W * C;
+        const int64_t img_off = (int64_t)n * H * W * C;
+        const uint8_t* img = in + img_off;
+        uint8_t* orow = out + (int64_t)row * W * C;
         const float fy = (float)oy;
-        uint8_t v[16];
-        const int x0 = xq * 4;
+        for (int xq = lane; xq < wq; xq += 64) {
+            const int x0 = xq * 4;
+            uint8_t v[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ox = x0 + i;
-            const float fx = (float)ox;
-            const float proj = (c0 * fx + c1 * fy) + 1.0f;
-            const float ix = ((a0 * fx + a1 * fy) + a2) / proj;
-            const float iy = ((b0 * fx + b1 * fy) + b2) / proj;
-            const float rx = roundf(ix), ry = roundf(iy);  // half away from zero
-            const bool ok = (proj != 0.0f) && (rx >= 0.0f) && (rx < (float)W) && (ry >= 0.0f) && (ry < (float)H);
-            const int64_t src = ok ? ((int64_t)(int)ry * W + (int)rx) * C : 0;
-            for (int c = 0; c < C; ++c) v[i * C + c] = ok ? img[src + c] : (uint8_t)fill;
-        }
-        if (C == 3 && (W & 3) == 0) {
-            uint8_t b[12];
+            for (int i = 0; i < 4; ++i) {
+                const float fx = (float)(x0 + i);
+                const float proj = (c0 * fx + c1 * fy) + 1.0f;
+                const float ix = ((a0 * fx + a1 * fy) + a2) / proj;
+                const float iy = ((b0 * fx + b1 * fy) + b2) / proj;
+                const float rx = roundf(ix), ry = roundf(iy);  // half away from zero
+                const bool ok = (proj != 0.0f) && (rx >= 0.0f) && (rx < (float)W) && (ry >= 0.0f) && (ry < (float)H);
+                const int64_t src = ok ? ((int64_t)(int)ry * W + (int)rx) * C : 0;
+                if (C == 3) {
+                    uint32_t w = ((uint32_t)fill) * 0x010101u;
+                    if (ok) {
+                        if (img_off + src + 4 <= total_bytes) w = reinterpret_cast<const u32_unaligned*>(img + src)->v;
+                        else w = (uint32_t)img[src] | ((uint32_t)img[src + 1] << 8) | ((uint32_t)img[src + 2] << 16);
+                    }
+                    v[i * 3 + 0] = w & 0xff; v[i * 3 + 1] = (w >> 8) & 0xff; v[i * 3 + 2] = (w >> 16) & 0xff;
+                } else {
+                    for (int c = 0; c < C; ++c) v[i * C + c] = ok ? img[src + c] : (uint8_t)fill;
+                }
+            }
+            if (C == 3 && (W & 3) == 0) {
+                uint8_t b[12];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) b[i] = v[i];
-            *reinterpret_cast<px4_t*>(orow + (int64_t)x0 * 3) = pack12(b);
-        } else {
-            for (int i = 0; i < 4; ++i)
-                if (x0 + i < W)
-                    for (int c = 0; c < C; ++c) orow[(int64_t)(x0 + i) * C + c] = v[i * C + c];
+                for (int i = 0; i < 12; ++i) b[i] = v[i];
+                *reinterpret_cast<px4_t*>(orow + (int64_t)x0 * 3) = pack12(b);
+            } else {
+                for (int i = 0; i < 4; ++i)
+                    if (x0 + i < W)
+                        for (int c = 0; c < C; ++c) orow[(int64_t)(x0 + i) * C + c] = v[i * C + c];
+            }
         }
     }
 }
 
 // ---- cutout (tfa.image.random_cutout with explicit centres), :495-499 -------------
+// One wave per image row: the rectangle test is per row + per quad, no per-thread division.
 __global__ void __launch_bounds__(256) cutout_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
                                                      int W, int C, const int32_t* __restrict__ centers, int half,
                                                      int value) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wq = (W + 3) >> 2;
-    const int64_t total = (int64_t)B * H * wq;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
-        const int xq = (int)(q % wq);
-        const int64_t r = q / wq;
-        const int y = (int)(r % H);
-        const int n = (int)(r / H);
+    const int rows = B * H;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int n = row / H, y = row - n * H;
         const int cy = centers[2 * n], cx = centers[2 * n + 1];
         const int y0 = max(0, cy - half), y1 = min(H, cy + half);
         const int xa = max(0, cx - half), xb = min(W, cx + half);
         const bool rowin = (y >= y0) && (y < y1);
-        const int64_t rowoff = ((int64_t)n * H + y) * (int64_t)W * C;
-        const int x0 = xq * 4;
-        if (C == 3 && (W & 3) == 0) {
-            px4_t p = *reinterpret_cast<const px4_t*>(in + rowoff + (int64_t)x0 * 3);
-            uint8_t b[12];
-            unpack12(p, b);
+        const int64_t rowoff = (int64_t)row * W * C;
+        for (int xq = lane; xq < wq; xq += 64) {
+            const int x0 = xq * 4;
+            if (C == 3 && (W & 3) == 0) {
+                px4_t p = *reinterpret_cast<const px4_t*>(in + rowoff + (int64_t)x0 * 3);
+                if (rowin && x0 + 3 >= xa && x0 < xb) {
+                    uint8_t b[12];
+                    unpack12(p, b);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool inside = rowin && (x0 + i >= xa) && (x0 + i < xb);
+                    for (int i = 0; i < 4; ++i) {
+                        const bool inside = (x0 + i >= xa) && (x0 + i < xb);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)value : b[3 * i + c];
-            }
-            *reinterpret_cast<px4_t*>(out + rowoff + (int64_t)x0 * 3) = pack12(b);
-        } else {
-            for (int i = 0; i < 4; ++i) {
-                const int x = x0 + i;
-                if (x >= W) break;
-                const bool inside = rowin && (x >= xa) && (x < xb);
-                for (int c = 0; c < C; ++c) {
-                    const int64_t o = rowoff + (int64_t)x * C + c;
-                    out[o] = inside ? (uint8_t)value : in[o];
+                        for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)value : b[3 * i + c];
+                    }
+                    p = pack12(b);
+                }
+                *reinterpret_cast<px4_t*>(out + rowoff + (int64_t)x0 * 3) = p;
+            } else {
+                for (int i = 0; i < 4; ++i) {
+                    const int x = x0 + i;
+                    if (x >= W) break;
+                    const bool inside = rowin && (x >= xa) && (x < xb);
+                    for (int c = 0; c < C; ++c) {
+                        const int64_t o = rowoff + (int64_t)x * C + c;
+                        out[o] = inside ? (uint8_t)value : in[o];
+                    }
                 }
             }
         }
@@ -417,44 +439,90 @@ __global__ void __launch_bounds__(256) lut_apply_kernel(const uint8_t* __restric
 }
 
 // ---- Sharpness (tfa.image.sharpness), :303-304 ---------------------------------------
-// One thread = 4 output pixels of one row; rows of the 3x3 window come through L1/L2.
+// One wave per row; a lane owns 4 output pixels and pulls the 3 x 6-pixel window it needs as 3 x 5 unaligned dword
+// loads (18 payload bytes per row) instead of 108 byte loads.  The 1-pixel border keeps the original.
 template <int MODE>  // 0: factor==0 (degenerate only), 1: 0<f<1 (no clip), 2: clip
+__device__ __forceinline__ uint8_t sharp_finish(uint8_t deg, uint8_t orig, float factor) {
+    if (MODE == 0) return deg;
+    if (MODE == 1) return blend1<false>(deg, orig, factor);
+    return blend1<true>(deg, orig, factor);
+}
+
+template <int MODE>
 __global__ void __launch_bounds__(256) sharpness_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
                                                         int W, int C, float factor) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wq = (W + 3) >> 2;
-    const int64_t total = (int64_t)B * H * wq;
+    const int rows = B * H;
+    const int64_t total_bytes = (int64_t)B * H * W * C;
     const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-        const int xq = (int)(q % wq);
-        const int64_t r = q / wq;
-        const int y = (int)(r % H);
-        const int n = (int)(r / H);
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int n = row / H, y = row - n * H;
         const uint8_t* img = in + (int64_t)n * H * W * C;
-        const int64_t rowoff = ((int64_t)n * H + y) * (int64_t)W * C;
+        const int64_t rowoff = (int64_t)row * W * C;
         const bool yin = (y >= 1) && (y < H - 1);
-        for (int i = 0; i < 4; ++i) {
-            const int x = xq * 4 + i;
-            if (x >= W) break;
-            const bool interior = yin && (x >= 1) && (x < W - 1);
-            for (int c = 0; c < C; ++c) {
-                const uint8_t orig = img[((int64_t)y * W + x) * C + c];
-                uint8_t deg = orig;
-                if (interior) {
-                    float acc = 0.0f;
+        for (int xq = lane; xq < wq; xq += 64) {
+            const int x0 = xq * 4;
+            if (C == 3 && (W & 3) == 0) {
+                // window bytes [s, s + 20) of rows y-1, y, y+1 with s = (x0 - 1) * 3 (relative to the row start)
+                uint8_t w[3][20];
 #pragma unroll
-                    for (int ky = -1; ky <= 1; ++ky)
+                for (int r = 0; r < 3; ++r) {
+                    const int yy = yin ? y + r - 1 : y;
+                    const int64_t base = ((int64_t)n * H + yy) * (int64_t)W * 3 + (int64_t)(x0 - 1) * 3;   // offset in the whole batch
 #pragma unroll
-                        for (int kx = -1; kx <= 1; ++kx) {
-                            const float v = (float)img[((int64_t)(y + ky) * W + (x + kx)) * C + c];
-                            acc = acc + v * ((ky == 0 && kx == 0) ? k5 : k1);
-                        }
-                    deg = trunc_u8(acc);
+                    for (int k = 0; k < 5; ++k) {
+                        const int64_t o = base + 4 * k;
+                        uint32_t v = 0;
+                        if (o >= 0 && o + 4 <= total_bytes) v = reinterpret_cast<const u32_unaligned*>(in + o)->v;
+                        else { for (int bb = 0; bb < 4; ++bb) if (o + bb >= 0 && o + bb < total_bytes) v |= (uint32_t)in[o + bb] << (8 * bb); }
+                        w[r][4 * k + 0] = v & 0xff; w[r][4 * k + 1] = (v >> 8) & 0xff; w[r][4 * k + 2] = (v >> 16) & 0xff; w[r][4 * k + 3] = v >> 24;
+                    }
                 }
-                uint8_t res;
-                if (MODE == 0) res = deg;
-                else if (MODE == 1) res = blend1<false>(deg, orig, factor);
-                else res = blend1<true>(deg, orig, factor);
-                out[rowoff + (int64_t)x * C + c] = res;
+                uint8_t b[12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int x = x0 + i;
+                    const bool interior = yin && (x >= 1) && (x < W - 1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint8_t orig = w[1][(i + 1) * 3 + c];
+                        uint8_t deg = orig;
+                        if (interior) {
+                            float acc = 0.0f;
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx) {
+                                    const float v = (float)w[ky][(i + kx) * 3 + c];
+                                    acc = acc + v * ((ky == 1 && kx == 1) ? k5 : k1);
+                                }
+                            deg = trunc_u8(acc);
+                        }
+                        b[3 * i + c] = sharp_finish<MODE>(deg, orig, factor);
+                    }
+                }
+                *reinterpret_cast<px4_t*>(out + rowoff + (int64_t)x0 * 3) = pack12(b);
+            } else {
+                for (int i = 0; i < 4; ++i) {
+                    const int x = x0 + i;
+                    if (x >= W) break;
+                    const bool interior = yin && (x >= 1) && (x < W - 1);
+                    for (int c = 0; c < C; ++c) {
+                        const uint8_t orig = img[((int64_t)y * W + x) * C + c];
+                        uint8_t deg = orig;
+                        if (interior) {
+                            float acc = 0.0f;
+                            for (int ky = -1; ky <= 1; ++ky)
+                                for (int kx = -1; kx <= 1; ++kx) {
+                                    const float v = (float)img[((int64_t)(y + ky) * W + (x + kx)) * C + c];
+                                    acc = acc + v * ((ky == 0 && kx == 0) ? k5 : k1);
+                                }
+                            deg = trunc_u8(acc);
+                        }
+                        out[rowoff + (int64_t)x * C + c] = sharp_finish<MODE>(deg, orig, factor);
+                    }
+                }
             }
         }
     }
@@ -622,8 +690,7 @@ int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, 
     if (!transform_host8 && !transforms_dev) return CHB_EINVAL;
     float t[8] = {1, 0, 0, 0, 1, 0, 0, 0};
     if (transform_host8) for (int i = 0; i < 8; ++i) t[i] = transform_host8[i];
-    const int64_t total = (int64_t)B * H * ((W + 3) / 4);
-    hipLaunchKernelGGL(affine_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
+    hipLaunchKernelGGL(affine_kernel, dim3(row_grid((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
                        transform_host8 ? nullptr : transforms_dev, per_image, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
                        fill & 0xff);
     CHB_LAUNCH_CHECK();
@@ -635,8 +702,7 @@ int chb_aug_cutout(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, 
     if (B == 0) return CHB_OK;
     if (!in || !out || !centers_dev || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     if (mask_size < 0 || (mask_size & 1)) return CHB_EINVAL;  // tfa: mask_size must be even
-    const int64_t total = (int64_t)B * H * ((W + 3) / 4);
-    hipLaunchKernelGGL(cutout_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
+    hipLaunchKernelGGL(cutout_kernel, dim3(row_grid((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
                        centers_dev, mask_size / 2, value & 0xff);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
@@ -681,8 +747,7 @@ int chb_aug_equalize(const uint8_t* in, uint8_t* out, int B, int H, int W, int C
 int chb_aug_sharpness(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, float factor, void* stream) {
     if (B == 0) return CHB_OK;
     if (!in || !out || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
-    const int64_t total = (int64_t)B * H * ((W + 3) / 4);
-    const int grid = stream_grid(total);
+    const int grid = row_grid((int64_t)B * H);
     hipStream_t s = (hipStream_t)stream;
     if (factor == 0.0f) hipLaunchKernelGGL(sharpness_kernel<0>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C, factor);
     else if (factor > 0.0f && factor < 1.0f) hipLaunchKernelGGL(sharpness_kernel<1>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C, factor);

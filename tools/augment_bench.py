@@ -1,0 +1,36 @@
+"""Achieved algorithmic GB/s of every augmentation kernel on a [256,224,224,3] uint8 batch (SURVEY §8d figures:
+2*H*W*3 bytes per image for single-pass ops, 3*H*W*3 for AutoContrast/Equalize, H*W*3*(1+out_bytes) for normalisation)."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from chambers_amd import augmentations as aug, kernels as K
+
+B, H, W = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 224, 224
+x = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda")
+px = B * H * W * 3
+centers = np.full((B, 2), 100, dtype=np.int32)
+cases = [
+    ("Invert", lambda: aug.Invert()(x), 2), ("Posterize", lambda: aug.Posterize(3)(x), 2), ("Solarize", lambda: aug.Solarize(230)(x), 2),
+    ("SolarizeAdd", lambda: aug.SolarizeAdd(99)(x), 2), ("Brightness", lambda: aug.Brightness(1.72)(x), 2),
+    ("Contrast", lambda: aug.Contrast(1.72)(x), 2), ("Color", lambda: aug.Color(1.72)(x), 2), ("Sharpness", lambda: aug.Sharpness(1.72)(x), 2),
+    ("ShearX", lambda: aug.ShearX(0.27, fill_value=128)(x, negate=False), 2), ("TranslateY", lambda: aug.TranslateY(90.0, fill_value=128)(x, negate=True), 2),
+    ("Rotate", lambda: aug.Rotate(27.0, fill_value=128)(x, negate=False), 2), ("CutOut", lambda: aug.CutOut(72, 128)(x, centers=centers), 2),
+    ("AutoContrast", lambda: aug.AutoContrast()(x), 3), ("Equalize", lambda: aug.Equalize()(x), 3),
+    ("Normalize_tf_f32", lambda: aug.ImageNetNormalization("tf")(x), 5), ("NormalizePatchify_bf16", lambda: K.normalize_patchify(x, 16, "tf"), 3),
+]
+out = {}
+for name, fn, mult in cases:
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 20
+    out[name] = {"us": round(ms * 1e3, 1), "algorithmic_GBps": round(mult * px / ms / 1e6, 1), "frac_of_8TBps": round(mult * px / ms / 1e6 / 8000, 3)}
+    print("%-24s %8.1f us  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, ms * 1e3, mult * px / ms / 1e6, 100 * mult * px / ms / 1e6 / 8000), flush=True)
+print(json.dumps(out))
