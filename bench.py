@@ -56,7 +56,9 @@ class KernelTimer:
             if not timer.enabled:
                 return orig_nt(a, b, out, m=m, **kw)
             mm = a.shape[0] if m is None else m
-            name = "gemm_nt_kernel<%d, %d>" % (kw.get("epilogue", 0), 1 if out.dtype == torch.float32 else 0)
+            # same selection rule as csrc/gemm.hip launch_nt(): persistent 256x256 tiles for large problems
+            fam = "gemm_nt256_kernel" if (mm >= 2048 and b.shape[0] >= 256) else "gemm_nt_kernel"
+            name = "%s<%d, %d>" % (fam, kw.get("epilogue", 0), 1 if out.dtype == torch.float32 else 0)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = orig_nt(a, b, out, m=m, **kw)
@@ -72,7 +74,8 @@ class KernelTimer:
             s.record()
             r = orig_tn(x, dy, dw, m=m)
             e.record()
-            timer.records.append(("gemm_tn_kernel", 2.0 * mm * x.shape[1] * dy.shape[1], s, e))
+            fam = "gemm_tn256_kernel" if (mm >= 4096 and x.shape[1] >= 128 and dy.shape[1] >= 128) else "gemm_tn_kernel"
+            timer.records.append((fam, 2.0 * mm * x.shape[1] * dy.shape[1], s, e))
             return r
 
         K.gemm_nt, K.gemm_tn = gemm_nt, gemm_tn
@@ -96,6 +99,8 @@ def draw_randaugment_decisions(gen, n_transforms, batch, h, w):
 
 
 def cpu_baseline(cfg_kwargs, sample_images=8, steps=2):
+    threads = max(1, min(16, os.cpu_count() or 1))      # the GPU box gives one GPU's share of host cores (16)
+    torch.set_num_threads(threads)
     """Oracle (CPU restatement of the TF2 reference) on the same workload shape: RandAugment(2,9) + normalise +
     ViT-B/16 forward + CE + backward + AdamW, fp32 torch-CPU, bounded to a few images."""
     from chambers_amd.engine import ViTConfig, init_keras_weights
