@@ -99,10 +99,10 @@ def draw_randaugment_decisions(gen, n_transforms, batch, h, w):
 
 
 def cpu_baseline(cfg_kwargs, sample_images=8, steps=2):
-    threads = max(1, min(16, os.cpu_count() or 1))      # the GPU box gives one GPU's share of host cores (16)
-    torch.set_num_threads(threads)
     """Oracle (CPU restatement of the TF2 reference) on the same workload shape: RandAugment(2,9) + normalise +
     ViT-B/16 forward + CE + backward + AdamW, fp32 torch-CPU, bounded to a few images."""
+    threads = max(1, min(16, os.cpu_count() or 1))      # the GPU box gives one GPU's share of host cores (16)
+    torch.set_num_threads(threads)
     from chambers_amd.engine import ViTConfig, init_keras_weights
     from oracle import augment_ref as A
     from oracle import rng_ref, vit_ref
@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-augment", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N ranks on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,12 +154,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (one process per GPU)" % args.gpus)
         args.gpus = world
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from chambers_amd import augmentations as aug
     from chambers_amd import kernels as K
