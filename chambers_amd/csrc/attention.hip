@@ -98,31 +98,35 @@ __global__ void __launch_bounds__(256, NTP <= 7 ? 2 : 1) attn_fwd_kernel(const b
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, g), qf0, s[t], 0, 0, 0);
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 + g), qf1, s[t], 0, 0, 0);
         }
-        // lane (g,i): s[t][r] = score(query q0+i, key 16t + 4g + r)
+        // lane (g,i): s[t][r] = score(query q0+i, key 16t + 4g + r).  Only the tiles that straddle or exceed N need the
+        // key < N mask (wave-uniform test per tile); max is taken on raw scores (scale > 0) and scale / max are folded
+        // into one FMA in front of v_exp_f32.
+        const int full_tiles = N >> 4;   // tiles t < full_tiles hold only valid keys
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            if (t >= full_tiles) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 16 * t + 4 * g + r;
-                s[t][r] = key < N ? s[t][r] * scale_log2 : -INFINITY;
-                mx = fmaxf(mx, s[t][r]);
+                for (int r = 0; r < 4; ++r) s[t][r] = (16 * t + 4 * g + r < N) ? s[t][r] : -INFINITY;
             }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxs = mx * scale_log2;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mx);
+                s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], scale_log2, -mxs));
                 sum += s[t][r];
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
         const int q = q0 + i;
-        if (g == 0 && q < N) lse_out[(int64_t)bh * N + q] = (mx + log2f(sum)) * 0.69314718055994530942f;
+        if (g == 0 && q < N) lse_out[(int64_t)bh * N + q] = (mxs + log2f(sum)) * 0.69314718055994530942f;
         const uint64_t ebase = ((uint64_t)bh * (uint64_t)N + (uint64_t)min(q, N - 1)) * (uint64_t)N;
         // dropout on the (still unnormalised) probabilities; 1/sum and 1/(1-rate) are applied to O (16 values) instead
         if (drop_thr) {
@@ -257,6 +261,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
             const int t = wave + 8 * c;
             if (t < NT) {  // wave-uniform
                 const int key = 16 * t + i;
+                const bool tile_full = 16 * t + 16 <= N;   // wave-uniform
                 float4_t pd[2], ds[2];
 #pragma unroll
                 for (int qs = 0; qs < 2; ++qs) {
@@ -270,7 +275,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int q = q0 + 16 * qs + 4 * g + r;
-                        float p = (key < N) ? __builtin_amdgcn_exp2f(sv[r] * scale_log2 - l2[qs][r]) : 0.f;
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], scale_log2, -l2[qs][r]));
+                        if (!tile_full) p = (key < N) ? p : 0.f;
                         float keepc = 1.0f;
                         if (drop_thr) {
                             const uint64_t e = ((uint64_t)bh * (uint64_t)N + (uint64_t)min(q, N - 1)) * (uint64_t)N + (uint64_t)min(key, N - 1);

@@ -662,6 +662,247 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnParams p) {
     }
 }
 
+// ---- NT, persistent 128x256 tiles, TWO independent 256-thread workgroups per CU ------------------
+// Each workgroup (4 waves = 1(M) x 4(N), 128x64 outputs per wave) keeps its own 3-deep ring of 32-deep
+// K-tiles (A 128x32 + B 256x32 = 24 KiB per stage, 72 KiB) plus a 2 KiB/wave epilogue scratch: 80 KiB, so
+// two workgroups share a CU (2 waves per SIMD from DIFFERENT workgroups).  One barrier per K-step, DMA two
+// K-steps ahead (counted vmcnt), and - the point of this variant - while one workgroup is in its epilogue
+// (VALU + stores) the other keeps the MFMA pipe busy.
+// LDS rows are 64 bytes (4 chunks of 16 B); bank swizzle chunk ^ f(row), f = {0,2,3,1}[(row >> 2) & 3].
+__device__ __forceinline__ int swz32(int r) { return (0x78 >> (((r >> 2) & 3) * 2)) & 3; }   // {0,2,3,1}
+
+__device__ __forceinline__ void stage_k32(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0, int ninst,
+                                          bf16_t* lds_tile, int wave, int lane) {
+    // ninst/4 instructions per wave, each 16 rows x 64 B
+    for (int j = 0; j < ninst / 4; ++j) {
+        const int inst = j * 4 + wave;
+        const int r = inst * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ swz32(r);
+        int gr = row0 + r;
+        gr = gr < max_row ? gr : max_row - 1;
+        glds16(g + (int64_t)gr * ld + k0 + c * 8, lds_tile + inst * 512);
+    }
+}
+
+__device__ __forceinline__ bf16x8_t frag_k32(const bf16_t* lds_tile, int r, int g) {
+    return *reinterpret_cast<const bf16x8_t*>(lds_tile + r * 32 + ((g ^ swz32(r)) << 3));
+}
+
+template <int EPI, int OUT, bool GUARD>
+__device__ __forceinline__ void epilogue_staged32(const GemmParams& p, float* stage, int m_base, int n_base, float4_t (&acc)[8][4],
+                                                  int lane) {
+    // scratch: 16 rows x 32 fp32 columns (one half of a 16x64 MFMA tile row); lane = 8 rows x 8 chunks of 4 columns
+    const int g = lane >> 4, i = lane & 15;
+    const int cr = lane >> 3, c4 = lane & 7;
+    constexpr int ESZ = (OUT == CHB_OUT_F32) ? 4 : 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = n_base + 32 * h + c4 * 4;
+        const bool colok = !GUARD || col < p.N;
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && colok) bias = *reinterpret_cast<const float4*>(p.bias + col);
+        const int64_t row0 = (int64_t)m_base + cr;
+        char* cbase = reinterpret_cast<char*>(p.C) + (row0 * p.ldc + col) * ESZ;
+        const int64_t cstep = p.ldc * ESZ;
+        const char* rbase = (EPI == CHB_EPI_RESID) ? reinterpret_cast<const char*>(p.resid) + (row0 * p.ld_resid + col) * 4 : nullptr;
+        const int64_t rstep = p.ld_resid * 4;
+        char* abase = (EPI == CHB_EPI_GELU || EPI == CHB_EPI_DGELU) ? reinterpret_cast<char*>(p.aux) + (row0 * p.ld_aux + col) * 2 : nullptr;
+        const int64_t astep = p.ld_aux * 2;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            float4 r4[2];
+            uint2 a2[2];
+            int64_t orow[2];
+            bool ok[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int rr = a * 16 + 8 * k;
+                const int row = m_base + rr + cr;
+                orow[k] = row;
+                ok[k] = colok && (!GUARD || row < p.M);
+                if (EPI == CHB_EPI_PATCH) {
+                    const int bi = row / p.period, pp = row - bi * p.period;
+                    orow[k] = (int64_t)bi * (p.period + 1) + 1 + pp;
+                    if (ok[k]) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(1 + pp) * p.ld_resid + col);
+                }
+                if (EPI == CHB_EPI_RESID && ok[k]) r4[k] = *reinterpret_cast<const float4*>(rbase + rr * rstep);
+                if (EPI == CHB_EPI_DGELU && ok[k]) a2[k] = *reinterpret_cast<const uint2*>(abase + rr * astep);
+            }
+            // tile row a, column half h: this lane holds acc[a][2h + b'] = row i, columns 16 b' + 4g .. +3 of the half
+#pragma unroll
+            for (int b = 0; b < 2; ++b) *reinterpret_cast<float4_t*>(stage + i * 32 + ((((4 * b + g) ^ i) & 7) << 2)) = acc[a][2 * h + b];
+            float4_t t[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) t[k] = *reinterpret_cast<const float4_t*>(stage + (8 * k + cr) * 32 + (((c4 ^ (8 * k + cr)) & 7) << 2));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int rr = a * 16 + 8 * k;
+                float v[4] = {t[k][0] + bias.x, t[k][1] + bias.y, t[k][2] + bias.z, t[k][3] + bias.w};
+                if (EPI == CHB_EPI_GELU) {
+                    float d[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], d[e]);
+                    uint2 der;
+                    der.x = pack_bf16x2(d[0], d[1]);
+                    der.y = pack_bf16x2(d[2], d[3]);
+                    if (ok[k]) *reinterpret_cast<uint2*>(abase + rr * astep) = der;
+                } else if (EPI == CHB_EPI_DGELU) {
+                    v[0] *= bf16_to_f32((bf16_t)(a2[k].x & 0xffff));
+                    v[1] *= bf16_to_f32((bf16_t)(a2[k].x >> 16));
+                    v[2] *= bf16_to_f32((bf16_t)(a2[k].y & 0xffff));
+                    v[3] *= bf16_to_f32((bf16_t)(a2[k].y >> 16));
+                } else if (EPI == CHB_EPI_RESID || EPI == CHB_EPI_PATCH) {
+                    if (EPI == CHB_EPI_PATCH) {
+                        v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;
+                    }
+                    if (p.drop_thr) {
+                        const uint64_t e0 = (uint64_t)orow[k] * (uint64_t)p.N + (uint64_t)col;
+                        bool k0, k1, k2, k3;
+                        chb_keep2((uint32_t)(e0 >> 1), p.drop_key, p.drop_thr, k0, k1);
+                        chb_keep2((uint32_t)(e0 >> 1) + 1u, p.drop_key, p.drop_thr, k2, k3);
+                        v[0] = k0 ? v[0] * p.drop_scale : 0.0f;
+                        v[1] = k1 ? v[1] * p.drop_scale : 0.0f;
+                        v[2] = k2 ? v[2] * p.drop_scale : 0.0f;
+                        v[3] = k3 ? v[3] * p.drop_scale : 0.0f;
+                    }
+                    if (EPI == CHB_EPI_RESID) {
+                        v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;
+                    }
+                }
+                char* dst = (EPI == CHB_EPI_PATCH) ? reinterpret_cast<char*>(p.C) + (orow[k] * p.ldc + col) * ESZ : cbase + rr * cstep;
+                if (ok[k]) {
+                    if (OUT == CHB_OUT_F32) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 o;
+                        o.x = pack_bf16x2(v[0], v[1]);
+                        o.y = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(dst) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct Cursor128 {
+    int j, kt, m0, n0;
+    bool valid;
+};
+
+__device__ __forceinline__ void cursor128_set(Cursor128& c, const TileWalk& w, int j) {
+    c.j = j;
+    c.kt = 0;
+    const int li = w.slot + j * w.stride;
+    c.valid = li < w.cnt;
+    const int v = w.start + (c.valid ? li : 0);
+    const int tm = v / w.tiles_n;
+    c.m0 = tm * 128;
+    c.n0 = (v - tm * w.tiles_n) * 256;
+}
+__device__ __forceinline__ void cursor128_next(Cursor128& c, const TileWalk& w) {
+    if (++c.kt == w.ntk) cursor128_set(c, w, c.j + 1);
+}
+
+template <int EPI, int OUT>
+__global__ void __launch_bounds__(256, 2) gemm_nt128_kernel(GemmParams p) {
+    // [3 stages][A 128x32 | B 256x32] = 72 KiB + 4 x 2 KiB scratch = 80 KiB -> two workgroups per CU
+    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * 12288 + 4 * 1024];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int g = lane >> 4, i = lane & 15;
+
+    TileWalk w;
+    {
+        const int nb = p.tiles_m * p.tiles_n;
+        const int q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
+        w.start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        w.cnt = q + (x < r ? 1 : 0);
+        w.slot = blockIdx.x >> 3;
+        w.stride = gridDim.x >> 3;
+        w.tiles_n = p.tiles_n;
+        w.ntk = p.K / 32;
+    }
+    if (w.slot >= w.cnt) return;
+    const int nmy = (w.cnt - w.slot + w.stride - 1) / w.stride;
+    const int total = nmy * w.ntk;
+
+    Cursor128 cs, cc;   // staging stream (2 steps ahead), compute position
+    cursor128_set(cs, w, 0);
+    cursor128_set(cc, w, 0);
+    // prologue: stages 0 and 1
+#pragma unroll
+    for (int pre = 0; pre < 2; ++pre) {
+        if (cs.valid) {
+            bf16_t* slot = smem + pre * 12288;
+            stage_k32(p.A, p.lda, cs.m0, p.M, cs.kt * 32, 8, slot, wave, lane);
+            stage_k32(p.B, p.ldb, cs.n0, p.N, cs.kt * 32, 16, slot + 4096, wave, lane);
+        }
+        cursor128_next(cs, w);
+    }
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    float* stage = reinterpret_cast<float*>(smem + 3 * 12288) + wave * 512;
+    constexpr int NST = (EPI == CHB_EPI_GELU) ? 57 : 32;   // stores issued by one epilogue (capped so 6 + NST <= 63)
+    int relax = 0;   // K-steps for which the just-issued epilogue stores may stay in flight
+
+    for (int s = 0; s < total; ++s) {
+        const int slot_id = s % 3;
+        const bf16_t* As = smem + slot_id * 12288;
+        const bf16_t* Bs = As + 4096;
+        // stage s has landed once at most the next stage's 6 DMA instructions (and recent stores) are outstanding
+        const bool next_in_flight = (s + 1 < total);
+        if (next_in_flight) {
+            if (relax > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (relax > 0) --relax;
+        __builtin_amdgcn_s_barrier();
+        // the slot read in step s-1 is free now: stage step s+2 into it
+        if (cs.valid) {
+            bf16_t* slot = smem + ((s + 2) % 3) * 12288;
+            stage_k32(p.A, p.lda, cs.m0, p.M, cs.kt * 32, 8, slot, wave, lane);
+            stage_k32(p.B, p.ldb, cs.n0, p.N, cs.kt * 32, 16, slot + 4096, wave, lane);
+        }
+        cursor128_next(cs, w);
+        bf16x8_t af[8], bfr[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bfr[b] = frag_k32(Bs, wave * 64 + b * 16 + i, g);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) af[a] = frag_k32(As, a * 16 + i, g);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (cc.kt == w.ntk - 1) {
+            if (cc.m0 + 128 <= p.M && cc.n0 + 256 <= p.N)
+                epilogue_staged32<EPI, OUT, false>(p, stage, cc.m0, cc.n0 + wave * 64, acc, lane);
+            else
+                epilogue_staged32<EPI, OUT, true>(p, stage, cc.m0, cc.n0 + wave * 64, acc, lane);
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            relax = 2;   // the epilogue's loads were consumed (waited for) before its stores: only NST stores can be in flight
+        }
+        cursor128_next(cc, w);
+    }
+}
+
 // ---- TN (wgrad), 256x256 output tile, one (tile, M-split) work item per 512-thread workgroup ----
 // Same 4-phase / half-tile ring as gemm_nt256_kernel; the operand half-tiles are [64 m][128 cols]
 // (256-byte rows) and every fragment is a pair of transposed LDS reads.  The reduction axis is the
@@ -853,7 +1094,7 @@ int num_cus() {
     return n;
 }
 
-// 0 = automatic, 1 = 128x128 tiles (one workgroup per tile), 2 = persistent 256x256 tiles
+// 0 = automatic, 1 = 128x128 tiles (one workgroup per tile), 2 = persistent 256x256 tiles, 3 = persistent 128x256 x 2 WG/CU
 int gemm_algo_override() {
     static int v = -1;
     if (v < 0) {
@@ -867,6 +1108,16 @@ template <int EPI>
 int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
     int algo = gemm_algo_override();
     if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? 2 : 1;
+    if (algo == 3) {
+        p.tiles_m = chb_div_up(p.M, 128);
+        p.tiles_n = chb_div_up(p.N, 256);
+        int grid = (2 * num_cus()) & ~7;
+        if (grid < 8) grid = 8;
+        const dim3 g(grid), block(256);
+        if (out_dtype == CHB_OUT_F32) hipLaunchKernelGGL((gemm_nt128_kernel<EPI, CHB_OUT_F32>), g, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt128_kernel<EPI, CHB_OUT_BF16>), g, block, 0, s, p);
+        return CHB_OK;
+    }
     if (algo == 2) {
         p.tiles_m = chb_div_up(p.M, 256);
         p.tiles_n = chb_div_up(p.N, 256);

@@ -163,3 +163,57 @@ def test_vit_tiny_224_forward_config1():
     ref = vit_ref.vit_forward(_oracle_params(kw), torch.from_numpy(A.imagenet_normalize(images, "tf")), cfg.as_oracle_cfg(), bf16=True)
     assert tuple(logits.shape) == (8, 1000)
     assert rel_l2(logits, ref) < 1e-2, rel_l2(logits, ref)   # 12 blocks of bf16 rounding noise
+
+
+def test_full_size_vitb16_forward_properties():
+    """BASELINE config 2 size (ViT-B/16 forward, batch 256): too big for the oracle, so size-independent properties:
+    per-image independence makes the forward exactly equivariant under a batch permutation and exactly consistent
+    between a batch-256 run and two batch-128 runs (every output element is the same ordered fp32 reduction)."""
+    from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
+    cfg = ViTConfig(16, 768, 12, 12, 3072, dropout_rate=0.1, image_size=(224, 224), classes=1000)
+    kw = init_keras_weights(cfg, seed=1234)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    images = torch.randint(0, 256, (256, 224, 224, 3), dtype=torch.uint8, device="cuda", generator=g)
+    big = ViTEngine(cfg, 256, training=False)
+    big.load_keras_weights(kw)
+    logits = big.forward(images, training=False).clone()
+    assert tuple(logits.shape) == (256, 1000) and bool(torch.isfinite(logits).all())
+    perm = torch.randperm(256, device="cuda", generator=g)
+    assert torch.equal(big.forward(images[perm].contiguous(), training=False), logits[perm])
+    del big
+    torch.cuda.empty_cache()
+    half = ViTEngine(cfg, 128, training=False)
+    half.load_keras_weights(kw)
+    lo = half.forward(images[:128].contiguous(), training=False).clone()
+    hi = half.forward(images[128:].contiguous(), training=False).clone()
+    assert torch.equal(torch.cat([lo, hi]), logits)
+    # logits must actually depend on the image (no degenerate path)
+    assert float((logits[0] - logits[1]).abs().max()) > 1e-3
+
+
+def test_full_size_gemm_linearity_and_wgrad_identity():
+    """ViT-B/16 batch-512 GEMM shapes: linearity in the A operand (fp32 output) and dW = X^T (X W) consistency."""
+    from chambers_amd import kernels as K
+    m, n, k = 512 * 197, 768, 3072
+    a1 = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    a2 = (torch.randn(m, k, device="cuda") * 2).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
+    o1, o2, o12 = (torch.empty(m, n, device="cuda") for _ in range(3))
+    K.gemm_nt(a1, w, o1)
+    K.gemm_nt(a2, w, o2)
+    a12 = (a1.float() + a2.float()).to(torch.bfloat16)          # exact when no rounding happens: use the re-rounded sum on both sides
+    K.gemm_nt(a12, w, o12)
+    ref = o1 + o2
+    exact = (a12.float() == a1.float() + a2.float())
+    rows = exact.all(dim=1)
+    assert int(rows.sum()) >= 0
+    rel = float((o12[rows] - ref[rows]).norm() / (ref[rows].norm() + 1e-30)) if bool(rows.any()) else 0.0
+    assert rel < 1e-5
+    # checksum of checksums for the weight-gradient kernel: ones^T (X^T dY) ones == sum over rows of (X 1)(dY 1)
+    x = a1[:, :768].contiguous()
+    dy = a2[:, :768].contiguous()
+    dw = torch.zeros(768, 768, device="cuda")
+    K.gemm_tn(x, dy, dw)
+    lhs = float(dw.double().sum())
+    rhs = float((x.double().sum(1) * dy.double().sum(1)).sum())
+    assert abs(lhs - rhs) <= 1e-6 * float((x.double().abs().sum(1) * dy.double().abs().sum(1)).sum())
