@@ -432,23 +432,27 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         bf16_t* nring = smem + ((s + 1) & 1) * 4 * 8192;
         const bf16_t* As = ring + wm * 8192;
         const bf16_t* Bs = ring + (2 + (wn >> 1)) * 8192;
-        bf16x8_t af[4][2], b0[2][2], b1[2][2];
+        bf16x8_t af[4][2], bq[4][2];
         const bool last_k = cc.kt == w.ntk - 1;
         const bool interior = cc.m0 + 256 <= p.M && cc.n0 + 256 <= p.N;
         float* stage = reinterpret_cast<float*>(smem + 2 * 4 * 8192) + wave * 1024;
 
-        // ---------------- phase 1: quadrant (rows 0-63, cols 0-31)
+        // ---------------- phase 1: rows 0-63 of the wave x all 64 columns (32 MFMAs).
+        // The other ring's A slots were last read in phase 2 of the previous step (before its barrier): restage them now.
+        if (ca.valid) {
+            stage_half(p.A, p.lda, ca.m0, p.M, ca.kt * BK, nring + 0 * 8192, wave, lane);
+            stage_half(p.A, p.lda, ca.m0 + 128, p.M, ca.kt * BK, nring + 1 * 8192, wave, lane);
+        }
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b0[b][ks] = frag_nt(Bs, b_row + b * 16, ks * 4 + g);
+            for (int ks = 0; ks < 2; ++ks) bq[b][ks] = frag_nt(Bs, b_row + b * 16, ks * 4 + g);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[a][ks] = frag_nt(As, a_row + a * 16, ks * 4 + g);
-        if (ca.valid) stage_half(p.A, p.lda, ca.m0, p.M, ca.kt * BK, nring + 0 * 8192, wave, lane);
-        __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave has consumed this step's B half-tiles
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -456,50 +460,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[b][ks], af[a][ks], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[b][ks], af[a][ks], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
 
-        // ---------------- phase 2: quadrant (rows 0-63, cols 32-63)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b1[b][ks] = frag_nt(Bs, b_row + 32 + b * 16, ks * 4 + g);
-        if (ca.valid) stage_half(p.A, p.lda, ca.m0 + 128, p.M, ca.kt * BK, nring + 1 * 8192, wave, lane);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[b][ks], af[a][ks], acc[a][2 + b], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-
-        // rows 0-63 of the wave are final after phase 2 of the tile's last K-step: their stores fly under phases 3-4
-        if (last_k) {
-            if (p.tiles_m > 0) {
-                if (interior) epilogue_staged<EPI, OUT, false, 0, 4>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
-                else epilogue_staged<EPI, OUT, true, 0, 4>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        // ---------------- phase 2: rows 64-127 (32 MFMAs).  This ring's B slots are free: stage step s+2 into them.
+        if (cb.valid) {
+            stage_half(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, ring + 2 * 8192, wave, lane);
+            stage_half(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, ring + 3 * 8192, wave, lane);
         }
-        // ---------------- phase 3: quadrant (rows 64-127, cols 32-63); B slots of this ring are free now
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[a][ks] = frag_nt(As, a_row + 64 + a * 16, ks * 4 + g);
-        if (cb.valid) stage_half(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, ring + 2 * 8192, wave, lane);
-        __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // retire everything but the B half-tiles of step s+2: all of step s+1 has landed when the barrier opens
+        if (cb.valid) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A half-tiles
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -507,41 +485,20 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[4 + a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[b][ks], af[a][ks], acc[4 + a][2 + b], 0, 0, 0);
+                for (int b = 0; b < 4; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[b][ks], af[a][ks], acc[4 + a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-
-        // ---------------- phase 4: quadrant (rows 64-127, cols 0-31); retire step s+1's loads
-        if (cb.valid) {
-            stage_half(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, ring + 3 * 8192, wave, lane);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[b][ks], af[a][ks], acc[4 + a][b], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
 
         cursor_next(ca, w);
         cursor_next(cb, w);
         // ---------------- end of an output tile: epilogue (later steps' loads keep flying)
         if (last_k) {
             if (p.tiles_m > 0) {
-                if (interior) epilogue_staged<EPI, OUT, false, 4, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
-                else epilogue_staged<EPI, OUT, true, 4, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+                if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+                else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             }
 #pragma unroll
-            for (int a = 4; a < 8; ++a)
+            for (int a = 0; a < 8; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
         }
