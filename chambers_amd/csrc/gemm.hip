@@ -34,6 +34,7 @@ struct GemmParams {
     float drop_scale; uint32_t drop_thr; uint32_t drop_key;
     int tiles_m, tiles_n;
     int stagger_ns;
+    float* colsum;   // optional fp32 [N]: += column sums of the output (bias gradient of the consumer layer)
 };
 
 // bijective XCD-aware remap: consecutive virtual ids (which share an A panel) stay on one XCD
@@ -245,6 +246,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
     const int64_t rstep = p.ld_resid * 4;
     char* abase = (EPI == CHB_EPI_GELU || EPI == CHB_EPI_DGELU) ? reinterpret_cast<char*>(p.aux) + (row0 * p.ld_aux + col) * 2 : nullptr;
     const int64_t astep = p.ld_aux * 2;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
     float* wr[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) wr[b] = stage + i * 64 + (((4 * b + g) ^ i) << 2);
@@ -322,7 +324,19 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
                     o.y = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(dst) = o;
                 }
+                csum[0] += v[0]; csum[1] += v[1]; csum[2] += v[2]; csum[3] += v[3];
             }
+        }
+    }
+    if (p.colsum) {   // this wave's 128 rows x 64 columns: fold the 4 row-groups (lanes cr) and add once per column
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            csum[e] += __shfl_xor(csum[e], 16, 64);
+            csum[e] += __shfl_xor(csum[e], 32, 64);
+        }
+        if (cr == 0 && colok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(p.colsum + col + e, csum[e]);
         }
     }
 }
@@ -1065,6 +1079,15 @@ template <int EPI>
 int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
     int algo = gemm_algo_override();
     if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? 2 : 1;
+    if (p.colsum && algo != 2) {
+        // only the persistent 256x256 kernel fuses the column sums; other paths add them with the stand-alone pass
+        if (out_dtype != CHB_OUT_BF16) return CHB_EUNSUPPORTED;
+        float* cs = p.colsum;
+        p.colsum = nullptr;
+        const int rc = launch_nt<EPI>(p, out_dtype, s);
+        if (rc != CHB_OK) return rc;
+        return chb_colsum_bf16(p.C, p.ldc, cs, p.M, p.N, (void*)s);
+    }
     if (algo == 3) {
         p.tiles_m = chb_div_up(p.M, 128);
         p.tiles_n = chb_div_up(p.N, 256);
@@ -1099,12 +1122,13 @@ extern "C" {
 
 int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                 const float* bias, int epilogue, int out_dtype, void* aux, int64_t ld_aux, const float* resid,
-                int64_t ld_resid, int period, float drop_rate, uint32_t drop_key, void* stream) {
+                int64_t ld_resid, int period, float drop_rate, uint32_t drop_key, float* out_colsum, void* stream) {
     if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return CHB_EINVAL;
     if (M == 0) return CHB_OK;
     if (K % BK != 0 || (N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3)) return CHB_EUNSUPPORTED;
     if (out_dtype != CHB_OUT_BF16 && out_dtype != CHB_OUT_F32) return CHB_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return CHB_EINVAL;
+    if (out_colsum && epilogue == CHB_EPI_PATCH) return CHB_EUNSUPPORTED;
     if ((epilogue == CHB_EPI_GELU || epilogue == CHB_EPI_DGELU) && (!aux || (ld_aux & 3))) return CHB_EINVAL;
     if ((epilogue == CHB_EPI_RESID || epilogue == CHB_EPI_PATCH) && (!resid || (ld_resid & 3))) return CHB_EINVAL;
     if (epilogue == CHB_EPI_PATCH && period <= 0) return CHB_EINVAL;
@@ -1118,13 +1142,15 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
     p.drop_key = drop_key;
     p.tiles_m = chb_div_up(M, BM); p.tiles_n = chb_div_up(N, BN);
     p.stagger_ns = 0;
+    p.colsum = out_colsum;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
-        case CHB_EPI_NONE: launch_nt<CHB_EPI_NONE>(p, out_dtype, s); break;
-        case CHB_EPI_GELU: launch_nt<CHB_EPI_GELU>(p, out_dtype, s); break;
-        case CHB_EPI_DGELU: launch_nt<CHB_EPI_DGELU>(p, out_dtype, s); break;
-        case CHB_EPI_RESID: launch_nt<CHB_EPI_RESID>(p, out_dtype, s); break;
-        case CHB_EPI_PATCH: launch_nt<CHB_EPI_PATCH>(p, out_dtype, s); break;
+        int rc;
+        case CHB_EPI_NONE: rc = launch_nt<CHB_EPI_NONE>(p, out_dtype, s); if (rc) return rc; break;
+        case CHB_EPI_GELU: rc = launch_nt<CHB_EPI_GELU>(p, out_dtype, s); if (rc) return rc; break;
+        case CHB_EPI_DGELU: rc = launch_nt<CHB_EPI_DGELU>(p, out_dtype, s); if (rc) return rc; break;
+        case CHB_EPI_RESID: rc = launch_nt<CHB_EPI_RESID>(p, out_dtype, s); if (rc) return rc; break;
+        case CHB_EPI_PATCH: rc = launch_nt<CHB_EPI_PATCH>(p, out_dtype, s); if (rc) return rc; break;
         default: return CHB_EINVAL;
     }
     CHB_LAUNCH_CHECK();

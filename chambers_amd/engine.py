@@ -468,9 +468,9 @@ class ViTEngine:
             pre = "encoder/layer_%d/" % l
             # MLP branch (self.dz = dropout-backward of dx at site_mlp(l))
             K.gemm_tn(a["u"], self.dz, self.g(pre + "dense2/kernel"), m=Mp)
-            K.gemm_nt(self.dz, self.wb(pre + "dense2/kernel"), self.da1, m=M, epilogue=K.EPI_DGELU, aux=a["a1"])
+            K.gemm_nt(self.dz, self.wb(pre + "dense2/kernel"), self.da1, m=M, epilogue=K.EPI_DGELU, aux=a["a1"],
+                      colsum=self.g(pre + "dense1/bias"))           # bias gradient of dense1 fused into the epilogue
             K.gemm_tn(a["h2"], self.da1, self.g(pre + "dense1/kernel"), m=Mp)
-            K.colsum(self.da1, self.g(pre + "dense1/bias"), m=M)
             K.gemm_nt(self.da1, self.wb(pre + "dense1/kernel"), self.dh, m=M)
             K.layernorm_bwd(self.dh, a["xmid"], d, a["mean2"], a["rstd2"], self.p(pre + "norm2/gamma"), self.dx, d, True,
                             self.g(pre + "norm2/gamma"), self.g(pre + "norm2/beta"), M, d, dz=self.dz,

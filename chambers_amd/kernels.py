@@ -141,9 +141,9 @@ def dropout_mask(n, rate, key, device="cuda"):
 
 
 # ------------------------------------------------------------------ ViT block
-def gemm_nt(a, b, out, m=None, bias=None, epilogue=EPI_NONE, aux=None, resid=None, period=0, drop_rate=0.0, drop_key=0):
+def gemm_nt(a, b, out, m=None, bias=None, epilogue=EPI_NONE, aux=None, resid=None, period=0, drop_rate=0.0, drop_key=0, colsum=None):
     """out[M,N] = epi(a[M,K] . b[N,K]^T); a, b bf16 2-D (row stride taken from the tensors)."""
-    _lib.require_gpu(a, b, out, bias, aux, resid)
+    _lib.require_gpu(a, b, out, bias, aux, resid, colsum)
     if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
         raise ValueError("gemm operands must be bfloat16")
     m = a.shape[0] if m is None else m
@@ -153,7 +153,7 @@ def gemm_nt(a, b, out, m=None, bias=None, epilogue=EPI_NONE, aux=None, resid=Non
     out_dtype = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
     _lib.call("chb_gemm_nt", _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), _lib.ptr(out), out.stride(0), int(m), int(n), int(k),
               _lib.ptr(bias), int(epilogue), out_dtype, _lib.ptr(aux), aux.stride(0) if aux is not None else 0, _lib.ptr(resid),
-              resid.stride(0) if resid is not None else 0, int(period), float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+              resid.stride(0) if resid is not None else 0, int(period), float(drop_rate), ctypes.c_uint32(int(drop_key)), _lib.ptr(colsum), _s())
     return out
 
 

@@ -109,10 +109,12 @@ int chb_dropout_mask(uint8_t* out, int64_t n, float rate, uint32_t key, void* st
  *  PATCH: rows are (image b, patch p) = row / period, row % period; written to row
  *         b*(period+1)+1+p of C; resid = positional table fp32 [period+1, ld_resid];
  *         dropout element index out_row*N+col.
+ * out_colsum (fp32 [N], optional): += column sums of C — the bias gradient of the layer that consumes C in the
+ * backward chain (fused into the epilogue; caller zeroes it once per step).
  * K % 64 == 0; M, N arbitrary (edges masked); A/B/C 16-byte aligned rows. */
 int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                 const float* bias, int epilogue, int out_dtype, void* aux, int64_t ld_aux, const float* resid,
-                int64_t ld_resid, int period, float drop_rate, uint32_t drop_key, void* stream);
+                int64_t ld_resid, int period, float drop_rate, uint32_t drop_key, float* out_colsum, void* stream);
 
 /* dW[Kd,Nd] += X[M,Kd]^T . dY[M,Nd]: weight gradient, bf16 operands, fp32 atomic accumulate
  * into dW (caller zeroes it once per step).  M % 64 == 0 (pad rows must be zero). */

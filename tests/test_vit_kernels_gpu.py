@@ -145,6 +145,21 @@ def test_gemm_nt_patch_epilogue_and_cls_row():
     assert rel_l2(x.cpu().reshape(bsz, npatch + 1, d), ref) < 2e-6
 
 
+@pytest.mark.parametrize("m,n,k", [(4096, 512, 128), (300, 256, 64), (2500, 320, 192)])
+def test_gemm_nt_fused_column_sums(m, n, k):
+    """out_colsum: the consumer layer's bias gradient, fused into the epilogue (persistent kernel) or added by the
+    stand-alone pass (small shapes) — same contract either way."""
+    from chambers_amd import kernels as K
+    a = bf(torch.randn(m, k, generator=g(25)))
+    b = bf(torch.randn(n, k, generator=g(26)) * 0.1)
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    cs = torch.full((n,), 3.0, device="cuda")
+    K.gemm_nt(a.cuda(), b.cuda(), out, colsum=cs)
+    ref = (a.double() @ b.double().t())
+    assert rel_l2(out.float().cpu(), ref) < 4e-3
+    assert rel_l2((cs - 3.0).cpu(), ref.sum(0)) < 2e-3       # sums of fp32 (fused) or bf16-rounded (stand-alone) outputs
+
+
 def test_gemm_nt_rejects_bad_shapes():
     from chambers_amd import kernels as K
     a = torch.zeros(8, 48, dtype=torch.bfloat16, device="cuda")
