@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(256, NTP <= 7 ? 2 : 1) attn_fwd_kernel(const b
 template <int NTP>
 __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, float scale,
-                                                       float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key) {
+                                                       float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key,
+                                                       float* __restrict__ dbias) {
     constexpr int NP = 32 * NTP, NT = 2 * NTP;
     constexpr int MT = (NT + 7) / 8;   // key tiles owned by one wave (wave w of 8: tiles w, w+8, ...)
     constexpr int DSLD = NP + 8;       // dS row stride (elements)
@@ -236,6 +237,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
             dv[dt][c] = (float4_t){0.f, 0.f, 0.f, 0.f};
         }
 
+    float4_t dqsum = (float4_t){0.f, 0.f, 0.f, 0.f};   // column sums of this wave's dQ tiles (bias gradient of the query projection)
     for (int it = 0; it < NTP; ++it) {
         const int q0 = 32 * it;
         bf16_t* dSb = dSs + (it & 1) * 32 * DSLD;
@@ -320,6 +322,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
                 w.x = pack_bf16x2(dq[0], dq[1]);
                 w.y = pack_bf16x2(dq[2], dq[3]);
                 *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * dtw + 4 * g) = w;
+                dqsum += dq;
             }
         }
     }
@@ -342,6 +345,37 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
                 *reinterpret_cast<uint2*>(vp + 16 * dt + 4 * g) = w;
             }
         }
+    }
+    if (dbias) {
+        // bias gradients of the fused QKV projection = column sums of dqkv over this head's rows: reduce over the 16 lanes
+        // that hold different queries / keys, then one atomic per (wave, column)
+        const int dtw = wave & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = dqsum[r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (i == 0) atomicAdd(dbias + h * HD + 16 * dtw + 4 * g + r, v);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float vk = 0.f, vv = 0.f;
+#pragma unroll
+                for (int c = 0; c < MT; ++c) {
+                    const int key = 16 * (wave + 8 * c) + i;
+                    if (wave + 8 * c < NT && key < N) {
+                        vk += dk[dt][c][r];
+                        vv += dv[dt][c][r];
+                    }
+                }
+                vk += __shfl_xor(vk, 1, 64); vk += __shfl_xor(vk, 2, 64); vk += __shfl_xor(vk, 4, 64); vk += __shfl_xor(vk, 8, 64);
+                vv += __shfl_xor(vv, 1, 64); vv += __shfl_xor(vv, 2, 64); vv += __shfl_xor(vv, 4, 64); vv += __shfl_xor(vv, 8, 64);
+                if (i == 0) {
+                    atomicAdd(dbias + Dm + h * HD + 16 * dt + 4 * g + r, vk);
+                    atomicAdd(dbias + 2 * Dm + h * HD + 16 * dt + 4 * g + r, vv);
+                }
+            }
     }
 }
 
@@ -379,7 +413,7 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
 }
 
 int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N, int H, int hd,
-                      float drop_rate, uint32_t drop_key, void* stream) {
+                      float drop_rate, uint32_t drop_key, float* dbias_qkv, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
     if (hd != HD || N > 224) return CHB_EUNSUPPORTED;  // backward keeps Q,K,V,dO of a head in LDS
     if (B == 0) return CHB_OK;
@@ -396,7 +430,7 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
             hipSuccess)                                                                                                          \
             return CHB_ELAUNCH;                                                                                                  \
         hipLaunchKernelGGL(attn_bwd_kernel<NTP>, grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
-                           lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key);                                      \
+                           lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);                           \
     } while (0)
     if (N <= 32) CHB_BWD(1);
     else if (N <= 64) CHB_BWD(2);

@@ -191,10 +191,10 @@ def attention_fwd(qkv, o, lse, b, n, h, hd, drop_rate=0.0, drop_key=0):
     return o
 
 
-def attention_bwd(qkv, o, d_o, lse, dqkv, b, n, h, hd, drop_rate=0.0, drop_key=0):
-    _lib.require_gpu(qkv, o, d_o, lse, dqkv)
+def attention_bwd(qkv, o, d_o, lse, dqkv, b, n, h, hd, drop_rate=0.0, drop_key=0, dbias=None):
+    _lib.require_gpu(qkv, o, d_o, lse, dqkv, dbias)
     _lib.call("chb_attention_bwd", _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(d_o), _lib.ptr(lse), _lib.ptr(dqkv), int(b), int(n), int(h), int(hd),
-              float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+              float(drop_rate), ctypes.c_uint32(int(drop_key)), _lib.ptr(dbias), _s())
     return dqkv
 
 

@@ -138,8 +138,9 @@ int chb_layernorm_bwd(const void* dy_bf16, const float* x, int64_t x_stride, con
  * o bf16 [B*N, H*hd]; lse fp32 [B,H,N]. hd == 64. Dropout element index ((b*H+h)*N+q)*N+k. */
 int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate,
                       uint32_t drop_key, void* stream);
+/* dbias_qkv (fp32 [3*H*hd], optional): += column sums of dqkv (bias gradient of the fused QKV projection). */
 int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N,
-                      int H, int hd, float drop_rate, uint32_t drop_key, void* stream);
+                      int H, int hd, float drop_rate, uint32_t drop_key, float* dbias_qkv, void* stream);
 
 /* ---------------------------------------------------------------- glue around the block */
 /* x[b,0,:] = dropout(cls + pos[0]) (ConcatEmbedding + LearnedEmbedding1D + Dropout,

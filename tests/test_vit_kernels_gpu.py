@@ -296,8 +296,12 @@ def test_attention_fwd_bwd(bsz, n, h, rate):
     do = bf(torch.randn(bsz * n, d, generator=g(41)))
     o_ref.backward(do.double())
     dqkv = torch.zeros(bsz * n, 3 * d, dtype=torch.bfloat16, device="cuda")
-    K.attention_bwd(qkv.cuda(), o, do.cuda(), lse, dqkv, bsz, n, h, 64, rate, key)
+    dbias = torch.zeros(3 * d, device="cuda")
+    K.attention_bwd(qkv.cuda(), o, do.cuda(), lse, dqkv, bsz, n, h, 64, rate, key, dbias=dbias)
     gref = qkv_ref.grad
+    rb = rel_l2(dbias.cpu()[d:], gref.sum(0)[d:])             # fused bias gradient (column sums); the key part is ~0 by symmetry
+    assert rel_l2(dbias.cpu()[:d], gref.sum(0)[:d]) < 1e-2 and rel_l2(dbias.cpu()[2 * d:], gref.sum(0)[2 * d:]) < 1e-2, rb
+    assert float(dbias[d:2 * d].abs().max()) < 2e-2 * float(dbias.abs().max() + 1e-6)
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         r = rel_l2(dqkv[:, sl].float().cpu(), gref[:, sl])
         assert r < 1e-2, "%s rel-l2 %g" % (name, r)

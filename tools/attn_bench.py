@@ -21,3 +21,10 @@ for rate in (0.0, 0.1):
     b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7))
     fl = 4.0 * B * H * N * N * 64
     print("rate %.1f  fwd %.3f ms (%.0f TF/s)   bwd %.3f ms (%.0f TF/s)" % (rate, f, fl / f / 1e9, b, 2.5 * fl / b / 1e9), flush=True)
+dbias = torch.zeros(3 * D, device="cuda")
+for rep in range(2):
+    b0 = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, 0.1, 7))
+    b1 = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, 0.1, 7, dbias=dbias))
+    cs = torch.zeros(3 * D, device="cuda")
+    b2 = t(lambda: K.colsum(dqkv, cs))
+    print("bwd no-bias %.3f ms | fused bias %.3f ms | separate colsum %.3f ms" % (b0, b1, b2))
