@@ -65,7 +65,7 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int NTP>  // pairs of 16-key tiles; padded key count = 32 * NTP
+template <int NTP, bool DROP>  // pairs of 16-key tiles; padded key count = 32 * NTP
 __global__ void __launch_bounds__(256, NTP <= 7 ? 2 : 1) attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse_out,
                                                        int N, int H, float scale_log2, float drop_scale, uint32_t drop_thr,
                                                        uint32_t drop_key) {
@@ -127,13 +127,13 @@ __global__ void __launch_bounds__(256, NTP <= 7 ? 2 : 1) attn_fwd_kernel(const b
         const float inv = 1.0f / sum;
         const int q = q0 + i;
         if (g == 0 && q < N) lse_out[(int64_t)bh * N + q] = (mxs + log2f(sum)) * 0.69314718055994530942f;
-        const uint64_t ebase = ((uint64_t)bh * (uint64_t)N + (uint64_t)min(q, N - 1)) * (uint64_t)N;
+        const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q, N - 1)) * (uint32_t)N;   // B*H*N*N < 2^32 (checked on the host)
         // dropout on the (still unnormalised) probabilities; 1/sum and 1/(1-rate) are applied to O (16 values) instead
-        if (drop_thr) {
+        if (DROP) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const uint64_t e0 = ebase + (uint64_t)(16 * t + 4 * g);
-                const uint32_t c0 = (uint32_t)(e0 >> 1), odd = (uint32_t)(e0 & 1);
+                const uint32_t e0 = ebase + (uint32_t)(16 * t + 4 * g);
+                const uint32_t c0 = e0 >> 1, odd = e0 & 1u;
                 const uint32_t h0 = chb_hash32(c0 ^ drop_key), h1 = chb_hash32((c0 + 1u) ^ drop_key), h2 = chb_hash32((c0 + 2u) ^ drop_key);
                 // element e0 + r uses 16-bit half ((odd + r) & 1) of hash (odd + r) >> 1
                 const uint32_t ue[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256, NTP <= 7 ? 2 : 1) attn_fwd_kernel(const b
                 }
             }
         }
-        const float oscale = drop_thr ? inv * drop_scale : inv;
+        const float oscale = DROP ? inv * drop_scale : inv;
         // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; k-slot (g, j): j<4 -> key 32u+4g+j, j>=4 -> key 32u+16+4g+(j-4)
         float4_t oacc[4];
 #pragma unroll
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256, NTP <= 7 ? 2 : 1) attn_fwd_kernel(const b
 // ------------------------------------------------------------------------------------ backward
 // LDS: K, V, Q, dO images [NP][64] (row-read swizzle; transposed reads take a 2-way conflict),
 // dS double buffer [2][32][NP + 8], lse*log2e and delta per query.
-template <int NTP>
+template <int NTP, bool DROP>
 __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, float scale,
                                                        float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key,
@@ -258,6 +258,12 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
                 l2[qs][r] = lse2[q0 + 16 * qs + 4 * g + r];
                 dl[qs][r] = delta[q0 + 16 * qs + 4 * g + r];
             }
+        uint32_t erow[2][4];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                erow[qs][r] = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + 16 * qs + 4 * g + r, N - 1)) * (uint32_t)N;
 #pragma unroll
         for (int c = 0; c < MT; ++c) {
             const int t = wave + 8 * c;
@@ -276,13 +282,15 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int q = q0 + 16 * qs + 4 * g + r;
                         float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], scale_log2, -l2[qs][r]));
                         if (!tile_full) p = (key < N) ? p : 0.f;
                         float keepc = 1.0f;
-                        if (drop_thr) {
-                            const uint64_t e = ((uint64_t)bh * (uint64_t)N + (uint64_t)min(q, N - 1)) * (uint64_t)N + (uint64_t)min(key, N - 1);
-                            keepc = chb_keep(e, drop_key, drop_thr) ? drop_scale : 0.f;
+                        if (DROP) {
+                            // element ((b*H+h)*N + q)*N + key as 32-bit arithmetic; one row base per (qs, r), one add per key
+                            const uint32_t e = erow[qs][r] + (uint32_t)min(key, N - 1);
+                            const uint32_t hsh = chb_hash32((e >> 1) ^ drop_key);
+                            const uint32_t u = (e & 1u) ? (hsh >> 16) : (hsh & 0xffffu);
+                            keepc = (u >= drop_thr) ? drop_scale : 0.f;
                         }
                         pd[qs][r] = p * keepc;                                   // dropped probabilities (for dV)
                         ds[qs][r] = p * (dp[r] * keepc - dl[qs][r]) * scale;     // d(scores) incl. 1/sqrt(hd)
@@ -392,6 +400,7 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
                       void* stream) {
     if (!qkv || !o || !lse || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
     if (hd != HD || N > 608) return CHB_EUNSUPPORTED;
+    if ((double)B * H * N * N >= 4294967296.0) return CHB_EUNSUPPORTED;   // dropout element index is 32-bit
     if (B == 0) return CHB_OK;
     const float scale_log2 = 1.44269504088896340736f / sqrtf((float)hd);
     const float ds = 1.0f / (1.0f - drop_rate);
@@ -400,7 +409,11 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* in = (const bf16_t*)qkv;
     bf16_t* out = (bf16_t*)o;
-#define CHB_FWD(NTP) hipLaunchKernelGGL(attn_fwd_kernel<NTP>, grid, block, 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key)
+#define CHB_FWD(NTP)                                                                                                      \
+    do {                                                                                                                  \
+        if (thr) hipLaunchKernelGGL((attn_fwd_kernel<NTP, true>), grid, block, 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key); \
+        else hipLaunchKernelGGL((attn_fwd_kernel<NTP, false>), grid, block, 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key);    \
+    } while (0)
     if (N <= 32) CHB_FWD(1);
     else if (N <= 64) CHB_FWD(2);
     else if (N <= 128) CHB_FWD(4);
@@ -416,6 +429,7 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
                       float drop_rate, uint32_t drop_key, float* dbias_qkv, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
     if (hd != HD || N > 224) return CHB_EUNSUPPORTED;  // backward keeps Q,K,V,dO of a head in LDS
+    if ((double)B * H * N * N >= 4294967296.0) return CHB_EUNSUPPORTED;
     if (B == 0) return CHB_OK;
     const float scale = 1.0f / sqrtf((float)hd);
     const float scale_log2 = 1.44269504088896340736f * scale;
@@ -426,10 +440,12 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
 #define CHB_BWD(NTP)                                                                                                             \
     do {                                                                                                                         \
         const size_t lds = bwd_lds_bytes<NTP>();                                                                                 \
-        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=      \
-            hipSuccess)                                                                                                          \
+        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
+            hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
             return CHB_ELAUNCH;                                                                                                  \
-        hipLaunchKernelGGL(attn_bwd_kernel<NTP>, grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
+        if (thr) hipLaunchKernelGGL((attn_bwd_kernel<NTP, true>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
+                           lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);                           \
+        else hipLaunchKernelGGL((attn_bwd_kernel<NTP, false>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
                            lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);                           \
     } while (0)
     if (N <= 32) CHB_BWD(1);
