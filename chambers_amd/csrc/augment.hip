@@ -155,89 +155,125 @@ __global__ void __launch_bounds__(256) affine_kernel(const uint8_t* __restrict__
     const int wq = (W + 3) >> 2;  // x-quads per row
     const int rows = B * H;
     const int64_t total_bytes = (int64_t)B * H * W * C;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const int n = row / H, oy = row - n * H;
-        float a0 = t0, a1 = t1, a2 = t2, b0 = t3, b1 = t4, b2 = t5, c0 = t6, c1 = t7;
-        if (tdev) {
-            const float* t = tdev + (per_image ? (int64_t)n * 8 : 0);
-            a0 = t[0]; a1 = t[1]; a2 = t[2]; b0 = t[3]; b1 = t[4]; b2 = t[5]; c0 = t[6]; c1 = t[7];
-        }
-        const int64_t img_off = (int64_t)n * H * W * C;
-        const uint8_t* img = in + img_off;
-        uint8_t* orow = out + (int64_t)row * W * C;
-        const float fy = (float)oy;
+    const bool fast = (C == 3) && ((W & 3) == 0);
+    // one wave per 4 consecutive output rows: 16 independent gathers in flight per lane
+    for (int row0 = (blockIdx.x * 4 + wave) * 4; row0 < rows; row0 += gridDim.x * 16) {
         for (int xq = lane; xq < wq; xq += 64) {
             const int x0 = xq * 4;
-            uint8_t v[16];
+            uint32_t w[4][4];
+            bool valid[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float fx = (float)(x0 + i);
-                const float proj = (c0 * fx + c1 * fy) + 1.0f;
-                const float ix = ((a0 * fx + a1 * fy) + a2) / proj;
-                const float iy = ((b0 * fx + b1 * fy) + b2) / proj;
-                const float rx = roundf(ix), ry = roundf(iy);  // half away from zero
-                const bool ok = (proj != 0.0f) && (rx >= 0.0f) && (rx < (float)W) && (ry >= 0.0f) && (ry < (float)H);
-                const int64_t src = ok ? ((int64_t)(int)ry * W + (int)rx) * C : 0;
-                if (C == 3) {
-                    uint32_t w = ((uint32_t)fill) * 0x010101u;
-                    if (ok) {
-                        if (img_off + src + 4 <= total_bytes) w = reinterpret_cast<const u32_unaligned*>(img + src)->v;
-                        else w = (uint32_t)img[src] | ((uint32_t)img[src + 1] << 8) | ((uint32_t)img[src + 2] << 16);
+            for (int k = 0; k < 4; ++k) {
+                const int row = row0 + k;
+                valid[k] = row < rows;
+                const int rr = valid[k] ? row : rows - 1;
+                const int n = rr / H, oy = rr - n * H;
+                float a0 = t0, a1 = t1, a2 = t2, b0 = t3, b1 = t4, b2 = t5, c0 = t6, c1 = t7;
+                if (tdev) {
+                    const float* t = tdev + (per_image ? (int64_t)n * 8 : 0);
+                    a0 = t[0]; a1 = t[1]; a2 = t[2]; b0 = t[3]; b1 = t[4]; b2 = t[5]; c0 = t[6]; c1 = t[7];
+                }
+                const int64_t img_off = (int64_t)n * H * W * C;
+                const uint8_t* img = in + img_off;
+                const float fy = (float)oy;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float fx = (float)(x0 + i);
+                    // affine rows (c0 == c1 == 0, every op of the augmentation schemes): proj is exactly 1 and x / 1 == x, so the
+                    // two IEEE divisions are skipped without changing a bit; true projective rows take the division path
+                    const bool affine_only = (c0 == 0.0f) && (c1 == 0.0f);
+                    const float proj = affine_only ? 1.0f : (c0 * fx + c1 * fy) + 1.0f;
+                    float ix = (a0 * fx + a1 * fy) + a2;
+                    float iy = (b0 * fx + b1 * fy) + b2;
+                    if (!affine_only) {
+                        ix = ix / proj;
+                        iy = iy / proj;
                     }
-                    v[i * 3 + 0] = w & 0xff; v[i * 3 + 1] = (w >> 8) & 0xff; v[i * 3 + 2] = (w >> 16) & 0xff;
-                } else {
-                    for (int c = 0; c < C; ++c) v[i * C + c] = ok ? img[src + c] : (uint8_t)fill;
+                    const float rx = roundf(ix), ry = roundf(iy);  // half away from zero
+                    const bool ok = (proj != 0.0f) && (rx >= 0.0f) && (rx < (float)W) && (ry >= 0.0f) && (ry < (float)H);
+                    const int64_t src = ok ? ((int64_t)(int)ry * W + (int)rx) * C : 0;
+                    uint32_t v = ((uint32_t)fill) * 0x01010101u;
+                    if (ok) {
+                        if (C == 3) {
+                            if (img_off + src + 4 <= total_bytes) v = reinterpret_cast<const u32_unaligned*>(img + src)->v;
+                            else v = (uint32_t)img[src] | ((uint32_t)img[src + 1] << 8) | ((uint32_t)img[src + 2] << 16);
+                        } else {
+                            v = 0;
+                            for (int c = 0; c < C; ++c) v |= (uint32_t)img[src + c] << (8 * c);
+                        }
+                    }
+                    w[k][i] = v;
                 }
             }
-            if (C == 3 && (W & 3) == 0) {
-                uint8_t b[12];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) b[i] = v[i];
-                *reinterpret_cast<px4_t*>(orow + (int64_t)x0 * 3) = pack12(b);
-            } else {
-                for (int i = 0; i < 4; ++i)
-                    if (x0 + i < W)
-                        for (int c = 0; c < C; ++c) orow[(int64_t)(x0 + i) * C + c] = v[i * C + c];
+            for (int k = 0; k < 4; ++k) {
+                if (!valid[k]) break;
+                uint8_t* orow = out + (int64_t)(row0 + k) * W * C;
+                if (fast) {
+                    uint8_t b[12];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        b[3 * i + 0] = w[k][i] & 0xff; b[3 * i + 1] = (w[k][i] >> 8) & 0xff; b[3 * i + 2] = (w[k][i] >> 16) & 0xff;
+                    }
+                    *reinterpret_cast<px4_t*>(orow + (int64_t)x0 * 3) = pack12(b);
+                } else {
+                    for (int i = 0; i < 4; ++i)
+                        if (x0 + i < W)
+                            for (int c = 0; c < C; ++c) orow[(int64_t)(x0 + i) * C + c] = (uint8_t)(w[k][i] >> (8 * c));
+                }
             }
         }
     }
 }
 
 // ---- cutout (tfa.image.random_cutout with explicit centres), :495-499 -------------
-// One wave per image row: the rectangle test is per row + per quad, no per-thread division.
+// One wave per 4 consecutive image rows (4 independent 12-byte loads in flight per lane, no per-thread division).
 __global__ void __launch_bounds__(256) cutout_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
                                                      int W, int C, const int32_t* __restrict__ centers, int half,
                                                      int value) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wq = (W + 3) >> 2;
     const int rows = B * H;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const int n = row / H, y = row - n * H;
-        const int cy = centers[2 * n], cx = centers[2 * n + 1];
-        const int y0 = max(0, cy - half), y1 = min(H, cy + half);
-        const int xa = max(0, cx - half), xb = min(W, cx + half);
-        const bool rowin = (y >= y0) && (y < y1);
-        const int64_t rowoff = (int64_t)row * W * C;
-        for (int xq = lane; xq < wq; xq += 64) {
-            const int x0 = xq * 4;
-            if (C == 3 && (W & 3) == 0) {
-                px4_t p = *reinterpret_cast<const px4_t*>(in + rowoff + (int64_t)x0 * 3);
-                if (rowin && x0 + 3 >= xa && x0 < xb) {
-                    uint8_t b[12];
-                    unpack12(p, b);
+    for (int row0 = (blockIdx.x * 4 + wave) * 4; row0 < rows; row0 += gridDim.x * 16) {
+        if (C == 3 && (W & 3) == 0) {
+            for (int xq = lane; xq < wq; xq += 64) {
+                const int x0 = xq * 4;
+                px4_t p[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bool inside = (x0 + i >= xa) && (x0 + i < xb);
+                for (int k = 0; k < 4; ++k)
+                    if (row0 + k < rows) p[k] = *reinterpret_cast<const px4_t*>(in + (int64_t)(row0 + k) * W * 3 + (int64_t)x0 * 3);
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)value : b[3 * i + c];
+                for (int k = 0; k < 4; ++k) {
+                    const int row = row0 + k;
+                    if (row >= rows) break;
+                    const int n = row / H, y = row - n * H;
+                    const int cy = centers[2 * n], cx = centers[2 * n + 1];
+                    const int xa = max(0, cx - half), xb = min(W, cx + half);
+                    const bool rowin = (y >= max(0, cy - half)) && (y < min(H, cy + half));
+                    if (rowin && x0 + 3 >= xa && x0 < xb) {
+                        uint8_t b[12];
+                        unpack12(p[k], b);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool inside = (x0 + i >= xa) && (x0 + i < xb);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)value : b[3 * i + c];
+                        }
+                        p[k] = pack12(b);
                     }
-                    p = pack12(b);
+                    *reinterpret_cast<px4_t*>(out + (int64_t)row * W * 3 + (int64_t)x0 * 3) = p[k];
                 }
-                *reinterpret_cast<px4_t*>(out + rowoff + (int64_t)x0 * 3) = p;
-            } else {
-                for (int i = 0; i < 4; ++i) {
-                    const int x = x0 + i;
-                    if (x >= W) break;
+            }
+        } else {
+            for (int k = 0; k < 4; ++k) {
+                const int row = row0 + k;
+                if (row >= rows) break;
+                const int n = row / H, y = row - n * H;
+                const int cy = centers[2 * n], cx = centers[2 * n + 1];
+                const int xa = max(0, cx - half), xb = min(W, cx + half);
+                const bool rowin = (y >= max(0, cy - half)) && (y < min(H, cy + half));
+                const int64_t rowoff = (int64_t)row * W * C;
+                for (int x = lane; x < W; x += 64) {
                     const bool inside = rowin && (x >= xa) && (x < xb);
                     for (int c = 0; c < C; ++c) {
                         const int64_t o = rowoff + (int64_t)x * C + c;
@@ -690,7 +726,7 @@ int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, 
     if (!transform_host8 && !transforms_dev) return CHB_EINVAL;
     float t[8] = {1, 0, 0, 0, 1, 0, 0, 0};
     if (transform_host8) for (int i = 0; i < 8; ++i) t[i] = transform_host8[i];
-    hipLaunchKernelGGL(affine_kernel, dim3(row_grid((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
+    hipLaunchKernelGGL(affine_kernel, dim3(row_grid(((int64_t)B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
                        transform_host8 ? nullptr : transforms_dev, per_image, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
                        fill & 0xff);
     CHB_LAUNCH_CHECK();
@@ -702,7 +738,7 @@ int chb_aug_cutout(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, 
     if (B == 0) return CHB_OK;
     if (!in || !out || !centers_dev || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
     if (mask_size < 0 || (mask_size & 1)) return CHB_EINVAL;  // tfa: mask_size must be even
-    hipLaunchKernelGGL(cutout_kernel, dim3(row_grid((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
+    hipLaunchKernelGGL(cutout_kernel, dim3(row_grid(((int64_t)B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
                        centers_dev, mask_size / 2, value & 0xff);
     CHB_LAUNCH_CHECK();
     return CHB_OK;

@@ -9,7 +9,7 @@ from chambers_amd import augmentations as aug, kernels as K
 B, H, W = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 224, 224
 x = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda")
 px = B * H * W * 3
-centers = np.full((B, 2), 100, dtype=np.int32)
+centers = torch.full((B, 2), 100, dtype=torch.int32, device="cuda")   # resident decisions: the H2D copy of a host array is not the kernel
 cases = [
     ("Invert", lambda: aug.Invert()(x), 2), ("Posterize", lambda: aug.Posterize(3)(x), 2), ("Solarize", lambda: aug.Solarize(230)(x), 2),
     ("SolarizeAdd", lambda: aug.SolarizeAdd(99)(x), 2), ("Brightness", lambda: aug.Brightness(1.72)(x), 2),
