@@ -33,7 +33,6 @@ struct GemmParams {
     int period;
     float drop_scale; uint32_t drop_thr; uint32_t drop_key;
     int tiles_m, tiles_n;
-    int stagger_ns;
     float* colsum;   // optional fp32 [N]: += column sums of the output (bias gradient of the consumer layer)
 };
 
@@ -392,7 +391,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
 
     TileWalk w;
     {
-        const int nb = (p.tiles_m < 0 ? -p.tiles_m : p.tiles_m) * p.tiles_n;
+        const int nb = p.tiles_m * p.tiles_n;
         const int q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
         w.start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
         w.cnt = q + (x < r ? 1 : 0);
@@ -402,11 +401,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         w.ntk = p.K / BK;
     }
     if (w.slot >= w.cnt) return;
-    if (p.stagger_ns > 0) {   // de-synchronise the CUs' epilogue bursts: phase group = slot & 3
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long ticks = (unsigned long long)((w.slot & 3) * p.stagger_ns) / 10;   // 100 MHz counter
-        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-    }
     const int nmy = (w.cnt - w.slot + w.stride - 1) / w.stride;
     const int total = nmy * w.ntk;
 
@@ -438,8 +432,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int a_row = i;                        // + mq*64 + a*16 within the wave's A half
-    const int b_row = (wn & 1) * 64 + i;        // + nq*32 + b*16 within the wave's B half
+    // Lane-constant LDS element offsets.  A tile row r = base + 16*a + i has swizzle ((r >> 1) & 7) = (i >> 1) & 7 for
+    // every a (16*a is a multiple of 16), so each fragment is one of four lane bases (A/B x k-step) plus a compile-time
+    // row offset: all address arithmetic leaves the K-loop.
+    const int sw = (i >> 1) & 7;
+    const int a_off0 = i * 64 + (((0 + g) ^ sw) << 3), a_off1 = i * 64 + (((4 + g) ^ sw) << 3);
+    const int b_off0 = ((wn & 1) * 64 + i) * 64 + (((0 + g) ^ sw) << 3), b_off1 = ((wn & 1) * 64 + i) * 64 + (((4 + g) ^ sw) << 3);
 
     for (int s = 0; s < total; ++s) {
         bf16_t* ring = smem + (s & 1) * 4 * 8192;
@@ -460,11 +458,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bq[b][ks] = frag_nt(Bs, b_row + b * 16, ks * 4 + g);
+            for (int ks = 0; ks < 2; ++ks) bq[b][ks] = *reinterpret_cast<const bf16x8_t*>(Bs + (ks ? b_off1 : b_off0) + b * 16 * 64);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[a][ks] = frag_nt(As, a_row + a * 16, ks * 4 + g);
+            for (int ks = 0; ks < 2; ++ks) af[a][ks] = *reinterpret_cast<const bf16x8_t*>(As + (ks ? a_off1 : a_off0) + a * 16 * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave has consumed this step's B half-tiles
         __builtin_amdgcn_sched_barrier(0);
@@ -486,7 +484,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[a][ks] = frag_nt(As, a_row + 64 + a * 16, ks * 4 + g);
+            for (int ks = 0; ks < 2; ++ks) af[a][ks] = *reinterpret_cast<const bf16x8_t*>(As + (ks ? a_off1 : a_off0) + (64 + a * 16) * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // retire everything but the B half-tiles of step s+2: all of step s+1 has landed when the barrier opens
         if (cb.valid) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -507,10 +505,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         cursor_next(cb, w);
         // ---------------- end of an output tile: epilogue (later steps' loads keep flying)
         if (last_k) {
-            if (p.tiles_m > 0) {
-                if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
-                else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
-            }
+            if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -548,6 +544,14 @@ __device__ __forceinline__ bf16x8_t frag_tn(const bf16_t* lds_tile, int mb, int 
     const bf16_t* a1 = lds_tile + r1 * 128 + ((chunk ^ swz_tn(r1)) << 3) + 4 * (pp & 1);
     const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a0);
     const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a1);
+    short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// the same fragment from a precomputed lane address: rows +0..3 at p, rows +4..7 at p + 4 rows
+__device__ __forceinline__ bf16x8_t frag_tn_at(const bf16_t* p) {
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)p);
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(p + 4 * 128));
     short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
 }
@@ -942,6 +946,18 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     const int ycol = (wn & 1) * 64;   // + nq*32 + b*16 within the wave's dY half
+    // Lane-constant LDS element offsets of the transposed reads.  For row r0 = 8g + q the swizzle is the same at r0 + 4 and
+    // r0 + 32, so one base per 16-column tile serves its four reads (rows +0, +4, +32, +36) with compile-time offsets.
+    int xo[8], yo[4];
+    {
+        const int q = i >> 2, pp = i & 3;
+        const int r0 = 8 * g + q;
+        const int sw = swz_tn(r0);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) xo[a] = r0 * 128 + ((((a * 16) >> 3) + (pp >> 1)) ^ sw) * 8 + 4 * (pp & 1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) yo[b] = r0 * 128 + ((((ycol + b * 16) >> 3) + (pp >> 1)) ^ sw) * 8 + 4 * (pp & 1);
+    }
 
     for (int s = 0; s < total; ++s) {
         bf16_t* ring = smem + (s & 1) * 4 * 8192;
@@ -956,11 +972,11 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) y0[b][ks] = frag_tn(Ys, ks * 32, ycol + b * 16, g, i);
+            for (int ks = 0; ks < 2; ++ks) y0[b][ks] = frag_tn_at(Ys + yo[b] + ks * 32 * 128);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn(Xs, ks * 32, a * 16, g, i);
+            for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[a] + ks * 32 * 128);
         if (have1) stage_half_tn(p.X, p.ldx, m1, k0, p.Kd, nring + 0 * 8192, wave, lane);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -980,7 +996,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) y1[b][ks] = frag_tn(Ys, ks * 32, ycol + 32 + b * 16, g, i);
+            for (int ks = 0; ks < 2; ++ks) y1[b][ks] = frag_tn_at(Ys + yo[2 + b] + ks * 32 * 128);
         if (have1) stage_half_tn(p.X, p.ldx, m1, k0 + 128, p.Kd, nring + 1 * 8192, wave, lane);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1000,7 +1016,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn(Xs, ks * 32, 64 + a * 16, g, i);
+            for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[4 + a] + ks * 32 * 128);
         if (have2) stage_half_tn(p.Y, p.ldy, m2, n0, p.Nd, ring + 2 * 8192, wave, lane);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1049,7 +1065,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int r = 0; r < 16; ++r) {
             const float v = stage[r * 64 + ((((lane >> 2) ^ r) << 2) | (lane & 3))];
             const int kd = k0 + wk * 128 + a * 16 + r;
-            if (kd < p.Kd && nd < p.Nd && p.splits > -1000) atomicAdd(p.W + (int64_t)kd * p.ldw + nd, v);
+            if (kd < p.Kd && nd < p.Nd) atomicAdd(p.W + (int64_t)kd * p.ldw + nd, v);
         }
     }
 }
@@ -1101,8 +1117,6 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
     if (algo == 2) {
         p.tiles_m = chb_div_up(p.M, 256);
         p.tiles_n = chb_div_up(p.N, 256);
-        if (getenv("CHB_DEBUG_NOEPI")) p.tiles_m = -p.tiles_m;  // timing experiment: skip the epilogue
-        { const char* e = getenv("CHB_GEMM_STAGGER_NS"); p.stagger_ns = e ? atoi(e) * (p.K / 64) : 0; }
         int grid = num_cus() & ~7;
         if (grid < 8) grid = 8;
         const dim3 g(grid), block(512);
@@ -1141,7 +1155,6 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
     p.drop_scale = 1.0f / (1.0f - drop_rate);
     p.drop_key = drop_key;
     p.tiles_m = chb_div_up(M, BM); p.tiles_n = chb_div_up(N, BN);
-    p.stagger_ns = 0;
     p.colsum = out_colsum;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
@@ -1178,9 +1191,7 @@ int chb_gemm_tn(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* 
             if (splits > steps) splits = steps;
             q.steps_per_split = chb_div_up(steps, splits);
             q.splits = chb_div_up(steps, q.steps_per_split);
-            const int nwg = tiles * q.splits;
-            if (getenv("CHB_DEBUG_NOEPI")) q.splits = -2000;
-            hipLaunchKernelGGL(gemm_tn256_kernel, dim3(nwg), dim3(512), 0, (hipStream_t)stream, q);
+            hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * q.splits), dim3(512), 0, (hipStream_t)stream, q);
             CHB_LAUNCH_CHECK();
             return CHB_OK;
         }
