@@ -238,9 +238,22 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
         }
 
     float4_t dqsum = (float4_t){0.f, 0.f, 0.f, 0.f};   // column sums of this wave's dQ tiles (bias gradient of the query projection)
-    for (int it = 0; it < NTP; ++it) {
+    // this wave's K / V row fragments (B operands of S and dP) never change across query blocks: keep them in registers
+    bf16x8_t kfr[MT][2], vfr[MT][2];
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int t = min(wave + 8 * c, NT - 1);
+            kfr[c][ks] = lds_row_frag(Ks, 16 * t + i, 4 * ks + g);
+            vfr[c][ks] = lds_row_frag(Vs, 16 * t + i, 4 * ks + g);
+        }
+    // round `it` runs phase A of query block `it` (scores, dS, dK/dV) and phase B of block `it - 1` (dQ from the dS tile
+    // published one round earlier) between the same pair of barriers: one barrier per block instead of two
+    for (int it = 0; it <= NTP; ++it) {
         const int q0 = 32 * it;
         bf16_t* dSb = dSs + (it & 1) * 32 * DSLD;
+        if (it < NTP) {
         // ---- phase A: this wave's key tiles against the 32 queries of the block
         bf16x8_t qa[2][2], ga[2][2];  // [query sub-tile][k-step]: A operands, rows = queries
 #pragma unroll
@@ -277,8 +290,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         // D[row = query 4g+r][col = key i]
-                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qs][ks], lds_row_frag(Ks, 16 * t + i, 4 * ks + g), sv, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[qs][ks], lds_row_frag(Vs, 16 * t + i, 4 * ks + g), dp, 0, 0, 0);
+                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qs][ks], kfr[c][ks], sv, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[qs][ks], vfr[c][ks], dp, 0, 0, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -313,9 +326,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
                     for (int r = 0; r < 4; ++r) dSb[(16 * qs + 4 * g + r) * DSLD + key] = f32_to_bf16(ds[qs][r]);
             }
         }
-        __syncthreads();
-        // ---- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; wave w owns query sub-tile w>>2, d-tile w&3
-        {
+        }   // phase A
+        // ---- phase B (block it - 1): dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; wave w owns query sub-tile w>>2, d-tile w&3
+        if (it > 0) {
+            const int q0 = 32 * (it - 1);
+            const bf16_t* dSb = dSs + ((it - 1) & 1) * 32 * DSLD;
             const int qs = wave >> 2, dtw = wave & 3;
             float4_t dq = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -333,6 +348,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
                 dqsum += dq;
             }
         }
+        __syncthreads();   // dS of block `it` is published; dS buffer (it - 1) & 1 is free for block it + 1
     }
     // dK^T / dV^T accumulators: lane (g,i) reg r = [d = 16dt + 4g + r][key = 16t + i]
 #pragma unroll
