@@ -6,7 +6,8 @@
 //             in-lane reduction + 2 shuffles), P^T feeds the P.V MFMA straight from the
 //             accumulators (k-order permuted on both operands), V^T via ds_read_b64_tr_b16.
 //   backward: each of 8 waves owns 1/8 of the key tiles and keeps dK^T/dV^T for them in registers
-//             across all query blocks; dS goes once through LDS for dQ.  No atomics.
+//             across all query blocks; dS goes once through LDS for dQ.  No atomics.  N > 224 takes
+//             the two-pass kernels further down (dK/dV per key chunk, dQ per query chunk).
 // Dropout on the probabilities uses the counter hash of common.hpp, element index
 // ((b*H + h)*N + q)*N + k, so forward and backward regenerate the same mask.
 //
@@ -403,6 +404,325 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------ backward, long sequences
+// N > 224 (ViT at 384^2: N = 577): Q, K, V, dO of a head no longer fit LDS together.  Two passes, no atomics, fp32
+// accumulation throughout (FlashAttention-2 style split):
+//   pass 1 (dK, dV): workgroup = (head, 128 keys); a wave keeps its 16 keys' K/V fragments and dK^T/dV^T in registers
+//                    and walks the query blocks, Q / dO / lse / delta streamed through a double-buffered LDS block.
+//   pass 2 (dQ)    : workgroup = (head, 128 queries); a wave keeps its 16 queries' Q / dO fragments in registers and
+//                    walks the key chunks (K / V double-buffered in LDS); scores are recomputed transposed
+//                    (S^T = K.Q^T) so dS^T feeds the dQ MFMA straight from the accumulators.
+
+// dropout keep factors for 4 consecutive elements e0 .. e0+3 (three hashes cover the 16-bit halves of both parities)
+__device__ __forceinline__ void keep4(uint32_t e0, uint32_t drop_key, uint32_t drop_thr, float drop_scale, float out[4]) {
+    const uint32_t c0 = e0 >> 1, odd = e0 & 1u;
+    const uint32_t h0 = chb_hash32(c0 ^ drop_key), h1 = chb_hash32((c0 + 1u) ^ drop_key), h2 = chb_hash32((c0 + 2u) ^ drop_key);
+    const uint32_t ue[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+    const uint32_t uo[4] = {h0 >> 16, h1 & 0xffffu, h1 >> 16, h2 & 0xffffu};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = ((odd ? uo[r] : ue[r]) >= drop_thr) ? drop_scale : 0.f;
+}
+
+__device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    float d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d += bf16_to_f32((bf16_t)(aw[k] & 0xffff)) * bf16_to_f32((bf16_t)(bw[k] & 0xffff));
+        d += bf16_to_f32((bf16_t)(aw[k] >> 16)) * bf16_to_f32((bf16_t)(bw[k] >> 16));
+    }
+    return d;
+}
+
+template <bool DROP>
+__global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                           const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale, float scale_log2,
+                                                           float drop_scale, uint32_t drop_thr, uint32_t drop_key,
+                                                           float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qb[2][32 * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t Gb[2][32 * HD];
+    __shared__ float l2b[2][32], dlb[2][32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const bf16_t* base = qkv + (int64_t)b * N * D3 + h * HD;
+    const bf16_t* obase = o + (int64_t)b * N * Dm + h * HD;
+    const bf16_t* gbase = d_o + (int64_t)b * N * Dm + h * HD;
+
+    const int kt0 = 128 * blockIdx.y + 16 * wave;    // first key of this wave's tile
+    const int key = kt0 + i;
+    const bool tile_live = kt0 < N, tile_full = kt0 + 16 <= N;   // wave-uniform
+    bf16x8_t kfr[2], vfr[2];
+    {
+        const bf16_t* kp = base + (int64_t)min(key, N - 1) * D3 + Dm;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kfr[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 32 * ks + 8 * g);
+            vfr[ks] = *reinterpret_cast<const bf16x8_t*>(kp + Dm + 32 * ks + 8 * g);
+        }
+    }
+    float4_t dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        dk[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        dv[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // staging roles: threads 0..255 bring dO (+ O for delta), threads 256..511 bring Q (+ lse); 8 threads per row
+    const int sr = (tid & 255) >> 3, sc = tid & 7;
+    const bool role_g = tid < 256;   // wave-uniform
+    uint4 sv0 = make_uint4(0, 0, 0, 0), sv1 = make_uint4(0, 0, 0, 0);
+    float sl = 0.f;
+    auto stage_load = [&](int q0) {
+        const int r = q0 + sr;
+        sv0 = make_uint4(0, 0, 0, 0);
+        sv1 = make_uint4(0, 0, 0, 0);
+        sl = INFINITY;
+        if (r < N) {
+            if (role_g) {
+                sv0 = *reinterpret_cast<const uint4*>(gbase + (int64_t)r * Dm + sc * 8);
+                sv1 = *reinterpret_cast<const uint4*>(obase + (int64_t)r * Dm + sc * 8);
+            } else {
+                sv0 = *reinterpret_cast<const uint4*>(base + (int64_t)r * D3 + sc * 8);
+                if (sc == 0) sl = lse[(int64_t)bh * N + r] * 1.44269504088896340736f;
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        bf16_t* dst = (role_g ? Gb[buf] : Qb[buf]) + sr * HD + ((sc ^ swz_row(sr)) << 3);
+        *reinterpret_cast<uint4*>(dst) = sv0;
+        if (role_g) {
+            float d = dot8_bf16(sv0, sv1);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (sc == 0) dlb[buf][sr] = d;
+        } else if (sc == 0) {
+            l2b[buf][sr] = sl;
+        }
+    };
+
+    const int nqb = (N + 31) >> 5;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int it = 0; it < nqb; ++it) {
+        const int cur = it & 1, q0 = 32 * it;
+        if (it + 1 < nqb) stage_load(q0 + 32);
+        if (tile_live) {
+            const bf16_t* Qs = Qb[cur];
+            const bf16_t* Gs = Gb[cur];
+            float4_t pd[2], ds[2];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                float4_t sv = (float4_t){0.f, 0.f, 0.f, 0.f}, dp = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    // D[row = query 4g+r][col = key i]
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Qs, 16 * qs + i, 4 * ks + g), kfr[ks], sv, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Gs, 16 * qs + i, 4 * ks + g), vfr[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = 16 * qs + 4 * g + r;
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], scale_log2, -l2b[cur][ql]));   // pad queries: lse = +inf -> 0
+                    if (!tile_full) p = (key < N) ? p : 0.f;
+                    float keepc = 1.0f;
+                    if (DROP) {
+                        const uint32_t e = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + ql, N - 1)) * (uint32_t)N + (uint32_t)min(key, N - 1);
+                        const uint32_t hsh = chb_hash32((e >> 1) ^ drop_key);
+                        const uint32_t u = (e & 1u) ? (hsh >> 16) : (hsh & 0xffffu);
+                        keepc = (u >= drop_thr) ? drop_scale : 0.f;
+                    }
+                    pd[qs][r] = p * keepc;
+                    ds[qs][r] = p * (dp[r] * keepc - dlb[cur][ql]) * scale;
+                }
+            }
+            // contraction over the 32 queries: k-slot (g, j): j<4 -> query 4g+j, j>=4 -> query 16+4g+(j-4)
+            const bf16x8_t pf = pack8(pd[0], pd[1]);
+            const bf16x8_t sf = pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t gt = lds_tr_frag<false>(Gs, 4 * g, 16 + 4 * g, 16 * dt, i);
+                const bf16x8_t qt = lds_tr_frag<false>(Qs, 4 * g, 16 + 4 * g, 16 * dt, i);
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dv[dt], 0, 0, 0);  // dV^T[d][key]
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sf, dk[dt], 0, 0, 0);  // dK^T[d][key]
+            }
+        }
+        if (it + 1 < nqb) stage_store(cur ^ 1);   // last read in round it - 1, all waves are past that barrier
+        __syncthreads();
+    }
+    // lane (g,i) reg r = [d = 16dt + 4g + r][key]
+    if (tile_live && key < N) {
+        bf16_t* kp = dqkv + ((int64_t)b * N + key) * D3 + Dm + h * HD;
+        bf16_t* vp = kp + Dm;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 w;
+            w.x = pack_bf16x2(dk[dt][0], dk[dt][1]);
+            w.y = pack_bf16x2(dk[dt][2], dk[dt][3]);
+            *reinterpret_cast<uint2*>(kp + 16 * dt + 4 * g) = w;
+            w.x = pack_bf16x2(dv[dt][0], dv[dt][1]);
+            w.y = pack_bf16x2(dv[dt][2], dv[dt][3]);
+            *reinterpret_cast<uint2*>(vp + 16 * dt + 4 * g) = w;
+        }
+    }
+    if (dbias && tile_live) {
+        const float live = key < N ? 1.f : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float vk = dk[dt][r] * live, vv = dv[dt][r] * live;
+                vk += __shfl_xor(vk, 1, 64); vk += __shfl_xor(vk, 2, 64); vk += __shfl_xor(vk, 4, 64); vk += __shfl_xor(vk, 8, 64);
+                vv += __shfl_xor(vv, 1, 64); vv += __shfl_xor(vv, 2, 64); vv += __shfl_xor(vv, 4, 64); vv += __shfl_xor(vv, 8, 64);
+                if (i == 0) {
+                    atomicAdd(dbias + Dm + h * HD + 16 * dt + 4 * g + r, vk);
+                    atomicAdd(dbias + 2 * Dm + h * HD + 16 * dt + 4 * g + r, vv);
+                }
+            }
+    }
+}
+
+template <bool DROP>
+__global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                          const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale, float scale_log2,
+                                                          float drop_scale, uint32_t drop_thr, uint32_t drop_key,
+                                                          float* __restrict__ dbias) {
+    constexpr int KC = 64;   // keys per staged chunk
+    __shared__ __attribute__((aligned(16))) bf16_t Kb[2][KC * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vb[2][KC * HD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const bf16_t* base = qkv + (int64_t)b * N * D3 + h * HD;
+
+    const int q0w = 128 * blockIdx.y + 16 * wave;
+    const int q = q0w + i, qc = min(q, N - 1);
+    const bool wave_live = q0w < N;   // wave-uniform
+    // B operands [k = d][col = query i] of S^T = K.Q^T and dP^T = V.dO^T; delta = sum_d dO*O
+    bf16x8_t qb[2], gb[2];
+    float dl = 0.f;
+    {
+        const bf16_t* qp = base + (int64_t)qc * D3;
+        const bf16_t* gp = d_o + ((int64_t)b * N + qc) * Dm + h * HD;
+        const bf16_t* op = o + ((int64_t)b * N + qc) * Dm + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qb[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 32 * ks + 8 * g);
+            const uint4 gv = *reinterpret_cast<const uint4*>(gp + 32 * ks + 8 * g);
+            const uint4 ov = *reinterpret_cast<const uint4*>(op + 32 * ks + 8 * g);
+            gb[ks] = __builtin_bit_cast(bf16x8_t, gv);
+            dl += dot8_bf16(gv, ov);
+        }
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+    }
+    const float l2 = lse[(int64_t)bh * N + qc] * 1.44269504088896340736f;
+    const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)N;
+
+    float4_t dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int sr = tid >> 3, sc = tid & 7;   // staging: 64 rows x 8 chunks, K and V
+    uint4 skv = make_uint4(0, 0, 0, 0), svv = make_uint4(0, 0, 0, 0);
+    auto stage_load = [&](int k0) {
+        const int r = k0 + sr;
+        skv = make_uint4(0, 0, 0, 0);
+        svv = make_uint4(0, 0, 0, 0);
+        if (r < N) {
+            const bf16_t* kp = base + (int64_t)r * D3 + Dm + sc * 8;
+            skv = *reinterpret_cast<const uint4*>(kp);
+            svv = *reinterpret_cast<const uint4*>(kp + Dm);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        const int off = sr * HD + ((sc ^ swz_row(sr)) << 3);
+        *reinterpret_cast<uint4*>(Kb[buf] + off) = skv;
+        *reinterpret_cast<uint4*>(Vb[buf] + off) = svv;
+    };
+
+    const int nkc = (N + KC - 1) / KC;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int cur = kc & 1, k0 = KC * kc;
+        if (kc + 1 < nkc) stage_load(k0 + KC);
+        if (wave_live) {
+            const bf16_t* Ks = Kb[cur];
+            const bf16_t* Vs = Vb[cur];
+#pragma unroll
+            for (int u = 0; u < KC / 32; ++u) {
+                if (k0 + 32 * u < N) {   // wave-uniform
+                    float4_t ds[2];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int t = 2 * u + hf;
+                        const int key0 = k0 + 16 * t + 4 * g;
+                        float4_t sv = (float4_t){0.f, 0.f, 0.f, 0.f}, dp = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            // D[row = key 4g+r][col = query i]
+                            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qb[ks], sv, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Vs, 16 * t + i, 4 * ks + g), gb[ks], dp, 0, 0, 0);
+                        }
+                        float keepc[4] = {1.f, 1.f, 1.f, 1.f};
+                        if (DROP) keep4(ebase + (uint32_t)key0, drop_key, drop_thr, drop_scale, keepc);
+                        const bool tile_full = k0 + 16 * t + 16 <= N;   // wave-uniform
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], scale_log2, -l2));
+                            if (!tile_full) p = (key0 + r < N) ? p : 0.f;
+                            ds[hf][r] = p * (dp[r] * keepc[r] - dl) * scale;
+                        }
+                    }
+                    // dQ^T[d][q] += K^T[d][key] dS^T[key][q]; k-slot (g, j): j<4 -> key 32u+4g+j, j>=4 -> key 32u+16+4g+(j-4)
+                    const bf16x8_t sf = pack8(ds[0], ds[1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8_t kt = lds_tr_frag<false>(Ks, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, i);
+                        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, sf, dq[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kc + 1 < nkc) stage_store(cur ^ 1);
+        __syncthreads();
+    }
+    // lane (g,i) reg r = dQ[query i][d = 16dt + 4g + r]
+    if (q < N) {
+        bf16_t* qp = dqkv + ((int64_t)b * N + q) * D3 + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 w;
+            w.x = pack_bf16x2(dq[dt][0], dq[dt][1]);
+            w.y = pack_bf16x2(dq[dt][2], dq[dt][3]);
+            *reinterpret_cast<uint2*>(qp + 16 * dt + 4 * g) = w;
+        }
+    }
+    if (dbias && wave_live) {
+        const float live = q < N ? 1.f : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = dq[dt][r] * live;
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (i == 0) atomicAdd(dbias + h * HD + 16 * dt + 4 * g + r, v);
+            }
+    }
+}
+
 template <int NTP>
 constexpr size_t bwd_lds_bytes() {
     return (size_t)(4 * 32 * NTP * HD + 2 * 32 * (32 * NTP + 8)) * sizeof(bf16_t) + (size_t)2 * 32 * NTP * sizeof(float);
@@ -444,7 +764,7 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
 int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N, int H, int hd,
                       float drop_rate, uint32_t drop_key, float* dbias_qkv, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
-    if (hd != HD || N > 224) return CHB_EUNSUPPORTED;  // backward keeps Q,K,V,dO of a head in LDS
+    if (hd != HD) return CHB_EUNSUPPORTED;
     if ((double)B * H * N * N >= 4294967296.0) return CHB_EUNSUPPORTED;
     if (B == 0) return CHB_OK;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -453,6 +773,26 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
     const uint32_t thr = drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u;
     const dim3 grid(B * H), block(512);
     hipStream_t s = (hipStream_t)stream;
+    // N <= 224: one pass with the whole head resident in LDS.  Longer sequences (or CHB_ATTN_BWD_ALGO=2, used by the
+    // parity tests to cross-check the two paths on the same input): dK/dV pass + dQ pass.
+    const char* algo_env = getenv("CHB_ATTN_BWD_ALGO");
+    const bool two_pass = N > 224 || (algo_env && atoi(algo_env) == 2);
+    if (two_pass) {
+        const dim3 grid2(B * H, (N + 127) / 128);
+        const bf16_t* a0 = (const bf16_t*)qkv;
+        const bf16_t* a1 = (const bf16_t*)o;
+        const bf16_t* a2 = (const bf16_t*)d_o;
+        bf16_t* out = (bf16_t*)dqkv;
+        if (thr) {
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid2, block, 0, s, a0, a1, a2, lse, out, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid2, block, 0, s, a0, a1, a2, lse, out, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid2, block, 0, s, a0, a1, a2, lse, out, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid2, block, 0, s, a0, a1, a2, lse, out, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);
+        }
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
 #define CHB_BWD(NTP)                                                                                                             \
     do {                                                                                                                         \
         const size_t lds = bwd_lds_bytes<NTP>();                                                                                 \
