@@ -47,6 +47,10 @@ PROTOTYPES = {
     "chb_dropout_bwd_bf16": [P, c_int64, P, c_int, c_int, c_float, c_uint32, P],
     "chb_colsum_bf16": [P, c_int64, P, c_int, c_int, P],
     "chb_softmax_ce": [P, c_int64, P, P, P, c_int64, c_int, c_int, c_float, P],
+    "chb_pool_tokens": [P, P, P, c_int, c_int, c_int, c_int, P],
+    "chb_pool_tokens_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
+    "chb_tanh_fwd": [P, P, c_int64, P],
+    "chb_tanh_bwd": [P, P, P, c_int64, P],
     "chb_cast_transpose": [P, P, P, P, c_int, c_int, P],
     "chb_adamw": [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P],
 }

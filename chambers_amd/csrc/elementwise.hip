@@ -193,6 +193,81 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// ---- token pooling over the patch tokens 1..N-1 (pooling="avg" | "max" | "sum"); one thread = one (image, column pair)
+__global__ void __launch_bounds__(256) pool_tokens_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ out, int32_t* __restrict__ argmax,
+                                                          int B, int N, int D, int mode) {
+    const int half = D >> 1;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * half) return;
+    const int b = (int)(idx / half), c = (int)(idx - (int64_t)b * half) * 2;
+    const bf16_t* p = h + (int64_t)b * N * D + c;
+    float a0 = mode == CHB_POOL_MAX ? -INFINITY : 0.f, a1 = a0;
+    int i0 = 1, i1 = 1;
+    for (int t = 1; t < N; ++t) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(p + (int64_t)t * D);
+        const float v0 = bf16_to_f32((bf16_t)(w & 0xffff)), v1 = bf16_to_f32((bf16_t)(w >> 16));
+        if (mode == CHB_POOL_MAX) {
+            if (v0 > a0) { a0 = v0; i0 = t; }
+            if (v1 > a1) { a1 = v1; i1 = t; }
+        } else {
+            a0 += v0;
+            a1 += v1;
+        }
+    }
+    if (mode == CHB_POOL_AVG) {
+        const float inv = 1.0f / (float)(N - 1);
+        a0 *= inv;
+        a1 *= inv;
+    }
+    *reinterpret_cast<uint32_t*>(out + (int64_t)b * D + c) = pack_bf16x2(a0, a1);
+    if (mode == CHB_POOL_MAX && argmax) {
+        argmax[(int64_t)b * D + c] = i0;
+        argmax[(int64_t)b * D + c + 1] = i1;
+    }
+}
+
+__global__ void __launch_bounds__(256) pool_tokens_bwd_kernel(const bf16_t* __restrict__ dout, const int32_t* __restrict__ argmax,
+                                                              bf16_t* __restrict__ dh, int B, int N, int D, int mode) {
+    const int half = D >> 1;
+    const int64_t total = (int64_t)B * N * half;
+    const float inv = 1.0f / (float)(N > 1 ? N - 1 : 1);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / half;
+        const int c = (int)(idx - row * half) * 2;
+        const int b = (int)(row / N), t = (int)(row - (int64_t)b * N);
+        uint32_t w = 0;
+        if (t > 0) {
+            const uint32_t g = *reinterpret_cast<const uint32_t*>(dout + (int64_t)b * D + c);
+            if (mode == CHB_POOL_SUM) {
+                w = g;
+            } else if (mode == CHB_POOL_AVG) {
+                w = pack_bf16x2(bf16_to_f32((bf16_t)(g & 0xffff)) * inv, bf16_to_f32((bf16_t)(g >> 16)) * inv);
+            } else {
+                const int2 a = *reinterpret_cast<const int2*>(argmax + (int64_t)b * D + c);
+                w = (a.x == t ? (g & 0xffffu) : 0u) | (a.y == t ? (g & 0xffff0000u) : 0u);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(dh + row * D + c) = w;
+    }
+}
+
+// ---- tanh feature head
+__global__ void __launch_bounds__(256) tanh_fwd_kernel(float* __restrict__ z, bf16_t* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = tanhf(z[i]);
+        z[i] = v;
+        if (y) y[i] = f32_to_bf16(v);
+    }
+}
+
+__global__ void __launch_bounds__(256) tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, bf16_t* __restrict__ dz,
+                                                       int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = y[i];
+        dz[i] = f32_to_bf16(dy[i] * (1.0f - v * v));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -241,6 +316,44 @@ int chb_colsum_bf16(const void* x, int64_t ld, float* out, int M, int N, void* s
     if (M == 0) return CHB_OK;
     hipLaunchKernelGGL(colsum_kernel, dim3(chb_div_up(N, 256), chb_div_up(M, 512)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
                        out, M, N);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_pool_tokens(const void* h, void* out, int32_t* argmax, int B, int N, int D, int mode, void* stream) {
+    if (B < 0 || N < 2 || D <= 0 || (D & 1) || mode < CHB_POOL_AVG || mode > CHB_POOL_SUM) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    if (!h || !out || (mode == CHB_POOL_MAX && !argmax)) return CHB_EINVAL;
+    hipLaunchKernelGGL(pool_tokens_kernel, dim3(chb_div_up((int64_t)B * (D / 2), 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                       (bf16_t*)out, argmax, B, N, D, mode);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_pool_tokens_bwd(const void* dout, const int32_t* argmax, void* dh, int B, int N, int D, int mode, void* stream) {
+    if (B < 0 || N < 2 || D <= 0 || (D & 1) || mode < CHB_POOL_AVG || mode > CHB_POOL_SUM) return CHB_EINVAL;
+    if (B == 0) return CHB_OK;
+    if (!dout || !dh || (mode == CHB_POOL_MAX && !argmax)) return CHB_EINVAL;
+    hipLaunchKernelGGL(pool_tokens_bwd_kernel, dim3(grid_for((int64_t)B * N * (D / 2))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, argmax, (bf16_t*)dh, B, N, D, mode);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_tanh_fwd(float* z, void* y_bf16, int64_t n, void* stream) {
+    if (n < 0) return CHB_EINVAL;
+    if (n == 0) return CHB_OK;
+    if (!z) return CHB_EINVAL;
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, (bf16_t*)y_bf16, n);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_tanh_bwd(const float* dy, const float* y, void* dz_bf16, int64_t n, void* stream) {
+    if (n < 0) return CHB_EINVAL;
+    if (n == 0) return CHB_OK;
+    if (!dy || !y || !dz_bf16) return CHB_EINVAL;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, (bf16_t*)dz_bf16, n);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

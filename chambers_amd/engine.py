@@ -44,6 +44,9 @@ class ViTConfig:
         if self.patch_dim % self.n_heads:
             raise ValueError("patch_dim must be divisible by n_heads")
         self.head_dim = self.patch_dim // self.n_heads
+        # GEMM-friendly widths of the two heads (zero-padded columns / rows; the pad never leaves the engine)
+        self.classes_pad = _round_up(self.classes, 64)
+        self.feature_pad = _round_up(int(feature_dim), 64) if feature_dim else 0
         self.grid = (self.image_size[0] // self.patch_size, self.image_size[1] // self.patch_size)
         self.n_patches = self.grid[0] * self.grid[1]
         self.n_tokens = self.n_patches + 1
@@ -51,7 +54,7 @@ class ViTConfig:
 
     def as_oracle_cfg(self):
         return {"patch_size": self.patch_size, "n_encoder_layers": self.n_encoder_layers, "n_heads": self.n_heads,
-                "dropout_rate": self.dropout_rate, "norm_epsilon": self.norm_epsilon, "pooling": self.pooling}
+                "dropout_rate": self.dropout_rate, "norm_epsilon": self.norm_epsilon, "pooling": None if self.pooling == "none" else self.pooling}
 
 
 class ParamSpec:
@@ -79,13 +82,13 @@ def build_param_table(cfg, decay_fn=None):
 
     start = off
     if cfg.include_top:
-        cpad = _round_up(cfg.classes, 64)
-        in_dim = cfg.feature_dim or d
+        cpad = cfg.classes_pad
+        in_dim = cfg.feature_pad or d
         add("predictions/kernel", (in_dim, cpad), True)
         add("predictions/bias", (cpad,), False)
     if cfg.feature_dim:
-        add("feature/kernel", (d, cfg.feature_dim), True)
-        add("feature/bias", (cfg.feature_dim,), False)
+        add("feature/kernel", (d, cfg.feature_pad), True)
+        add("feature/bias", (cfg.feature_pad,), False)
     add("encoder/norm/gamma", (d,), False)
     add("encoder/norm/beta", (d,), False)
     buckets.append((start, off))
@@ -139,13 +142,16 @@ def keras_to_internal(kw, cfg):
     out["encoder/norm/gamma"] = np.asarray(kw["encoder/norm/gamma"])
     out["encoder/norm/beta"] = np.asarray(kw["encoder/norm/beta"])
     if cfg.feature_dim:
-        out["feature/kernel"] = np.asarray(kw["feature/kernel"])
-        out["feature/bias"] = np.asarray(kw["feature/bias"])
+        fk = np.zeros((d, cfg.feature_pad), dtype=np.float32)
+        fk[:, :cfg.feature_dim] = np.asarray(kw["feature/kernel"])
+        fb = np.zeros((cfg.feature_pad,), dtype=np.float32)
+        fb[:cfg.feature_dim] = np.asarray(kw["feature/bias"])
+        out["feature/kernel"], out["feature/bias"] = fk, fb
     if cfg.include_top:
-        cpad = _round_up(cfg.classes, 64)
+        cpad = cfg.classes_pad
         k = np.asarray(kw["predictions/kernel"])
-        kp = np.zeros((k.shape[0], cpad), dtype=np.float32)
-        kp[:, :cfg.classes] = k
+        kp = np.zeros((cfg.feature_pad or d, cpad), dtype=np.float32)
+        kp[:k.shape[0], :cfg.classes] = k
         bp = np.zeros((cpad,), dtype=np.float32)
         bp[:cfg.classes] = np.asarray(kw["predictions/bias"])
         out["predictions/kernel"], out["predictions/bias"] = kp, bp
@@ -175,9 +181,9 @@ def internal_to_keras(iw, cfg):
     out["encoder/norm/gamma"] = iw["encoder/norm/gamma"]
     out["encoder/norm/beta"] = iw["encoder/norm/beta"]
     if cfg.feature_dim:
-        out["feature/kernel"], out["feature/bias"] = iw["feature/kernel"], iw["feature/bias"]
+        out["feature/kernel"], out["feature/bias"] = iw["feature/kernel"][:, :cfg.feature_dim], iw["feature/bias"][:cfg.feature_dim]
     if cfg.include_top:
-        out["predictions/kernel"] = iw["predictions/kernel"][:, :cfg.classes]
+        out["predictions/kernel"] = iw["predictions/kernel"][:cfg.feature_dim or d, :cfg.classes]
         out["predictions/bias"] = iw["predictions/bias"][:cfg.classes]
     return {k: np.ascontiguousarray(v) for k, v in out.items()}
 
@@ -256,8 +262,10 @@ class ViTEngine:
         self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if cfg.head_dim != 64:
             raise ValueError("attention kernels are built for head_dim 64 (all reference ViT configs), got %d" % cfg.head_dim)
-        if cfg.pooling != "cls":
-            raise ValueError("the engine implements pooling='cls' (vision_transformer.py:182-189); got %r" % (cfg.pooling,))
+        if cfg.pooling not in ("cls", "avg", "max", "sum", "none"):
+            raise ValueError("pooling must be one of 'cls', 'avg', 'max', 'sum', None (vision_transformer.py:172-191); got %r" % (cfg.pooling,))
+        if cfg.pooling == "none" and (cfg.include_top or cfg.feature_dim):
+            raise ValueError("pooling=None returns the token sequence; heads on the token axis are not built (use a pooling mode)")
         self.specs, self.n_params_padded, self.buckets = build_param_table(cfg, decay_fn)
         self.by_name = {s.name: s for s in self.specs}
         dev, f32, bf = self.dev, torch.float32, torch.bfloat16
@@ -348,14 +356,26 @@ class ViTEngine:
                 "h1": z(Mp, d), "mean1": z(Mp, dtype=f32), "rstd1": z(Mp, dtype=f32), "qkv": z(Mp, 3 * d), "o": z(Mp, d),
                 "lse": z(B * cfg.n_heads * n, dtype=f32), "xmid": z(Mp, d, dtype=f32), "h2": z(Mp, d), "mean2": z(Mp, dtype=f32),
                 "rstd2": z(Mp, dtype=f32), "a1": z(Mp, ff), "u": z(Mp, ff)})
-        self.hf = z(self.Bp, d)
-        self.meanf, self.rstdf = z(self.Bp, dtype=f32), z(self.Bp, dtype=f32)
+        self.hf = z(self.Bp, d)                      # pooled, normalised embedding (bf16 operand of the heads)
+        nstat = self.Bp if cfg.pooling == "cls" else Mp
+        self.meanf, self.rstdf = z(nstat, dtype=f32), z(nstat, dtype=f32)
+        if cfg.pooling != "cls":
+            self.hn = z(Mp, d)                       # final LayerNorm over every token (avg / max / sum pooling)
+            self.pool_arg = torch.zeros(self.Bp, d, dtype=torch.int32, device=dev) if cfg.pooling == "max" else None
+        F = cfg.feature_pad
+        if F:
+            self.feat = z(self.Bp, F, dtype=f32)     # tanh(feature) — the model output when include_top=False
+            self.feat_b = z(self.Bp, F)
         if cfg.include_top:
-            self.cpad = _round_up(cfg.classes, 64)
+            self.cpad = cfg.classes_pad
             self.logits = z(self.Bp, self.cpad, dtype=f32)
         self.loss_vec = z(self.Bp, dtype=f32)
         if self.training:
-            self.dlogits = z(self.Bp, self.cpad)
+            if cfg.include_top:
+                self.dlogits = z(self.Bp, self.cpad)
+            if F:
+                self.dfeat = z(self.Bp, F, dtype=f32)
+                self.dfz = z(self.Bp, F)
             self.dhf = z(self.Bp, d)
             self.dx = z(Mp, d, dtype=f32)
             self.dz = z(Mp, d)
@@ -429,14 +449,24 @@ class ViTEngine:
             x = x_out
         self.x_final = x
         d, n = cfg.patch_dim, cfg.n_tokens
-        # final LayerNorm only where it is consumed: the cls rows (row stride n*d)
-        K.layernorm_fwd(x, n * d, self.p("encoder/norm/gamma"), self.p("encoder/norm/beta"), self.hf, self.meanf, self.rstdf, self.B, d,
-                        cfg.norm_epsilon)
+        if cfg.pooling == "cls":
+            # final LayerNorm only where it is consumed: the cls rows (row stride n*d)
+            K.layernorm_fwd(x, n * d, self.p("encoder/norm/gamma"), self.p("encoder/norm/beta"), self.hf, self.meanf, self.rstdf, self.B, d,
+                            cfg.norm_epsilon)
+        else:
+            K.layernorm_fwd(x, d, self.p("encoder/norm/gamma"), self.p("encoder/norm/beta"), self.hn, self.meanf, self.rstdf, self.M, d,
+                            cfg.norm_epsilon)
+            if cfg.pooling == "none":
+                return self.hn[:self.M].view(self.B, n, d)
+            K.pool_tokens(self.hn, self.hf, self.pool_arg, self.B, n, d, cfg.pooling)
+        head_in = self.hf
         if cfg.feature_dim:
-            raise NotImplementedError("feature (tanh) head is not built into the engine yet")
+            K.gemm_nt(self.hf, self.wbt("feature/kernel"), self.feat, m=self.B, bias=self.p("feature/bias"))
+            K.tanh_fwd(self.feat, self.feat_b)
+            head_in = self.feat_b
         if not cfg.include_top:
-            return self.hf[:self.B]
-        K.gemm_nt(self.hf, self.wbt("predictions/kernel"), self.logits, m=self.B, bias=self.p("predictions/bias"))
+            return self.feat[:self.B, :cfg.feature_dim] if cfg.feature_dim else self.hf[:self.B]
+        K.gemm_nt(head_in, self.wbt("predictions/kernel"), self.logits, m=self.B, bias=self.p("predictions/bias"))
         return self.logits[:self.B, :cfg.classes]
 
     def loss(self, labels):
@@ -446,19 +476,45 @@ class ViTEngine:
         return self.loss_vec[:self.B]
 
     # ---- backward -------------------------------------------------------------------------
-    def backward(self):
+    def backward(self, doutput=None):
+        """Backward of the last forward.  With a top, the gradient starts at dlogits (filled by `loss`); a headless model
+        (include_top=False: pooled embedding or tanh feature as output) takes d(loss)/d(output) fp32 [B, F] as `doutput`."""
         cfg = self.cfg
         rate, key = self._keys(True)
         d, ff, n, M, Mp = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens, self.M, self.Mp
         L = cfg.n_encoder_layers
+        F = cfg.feature_dim
         self.G.zero_()
         self.dx.zero_()
-        # head + final norm
-        K.gemm_tn(self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp)
-        K.colsum(self.dlogits, self.g("predictions/bias"), m=self.B)
-        K.gemm_nt(self.dlogits, self.wb("predictions/kernel"), self.dhf, m=self.B)
-        K.layernorm_bwd(self.dhf, self.x_final, n * d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, n * d, False,
-                        self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
+        # heads
+        if cfg.include_top:
+            if doutput is not None:
+                raise ValueError("doutput is for include_top=False models; with a top the gradient comes from loss()")
+            K.gemm_tn(self.feat_b if F else self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp)
+            K.colsum(self.dlogits, self.g("predictions/bias"), m=self.B)
+            K.gemm_nt(self.dlogits, self.wb("predictions/kernel"), self.dfeat if F else self.dhf, m=self.B)
+        elif cfg.pooling == "none":
+            if doutput is None or tuple(doutput.shape) != (self.B, n, d):
+                raise ValueError("pooling=None: pass doutput of shape %s" % ((self.B, n, d),))
+            self.dh[:M].copy_(doutput.reshape(M, d))
+        else:
+            if doutput is None or tuple(doutput.shape) != (self.B, F or d):
+                raise ValueError("include_top=False: pass doutput of shape %s" % ((self.B, F or d),))
+            (self.dfeat[:self.B, :F] if F else self.dhf[:self.B]).copy_(doutput)
+        if F:
+            K.tanh_bwd(self.dfeat, self.feat, self.dfz)
+            K.gemm_tn(self.hf, self.dfz, self.g("feature/kernel"), m=self.Bp)
+            K.colsum(self.dfz, self.g("feature/bias"), m=self.B)
+            K.gemm_nt(self.dfz, self.wb("feature/kernel"), self.dhf, m=self.B)
+        # pooling + final norm
+        if cfg.pooling == "cls":
+            K.layernorm_bwd(self.dhf, self.x_final, n * d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, n * d, False,
+                            self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
+        else:
+            if cfg.pooling != "none":
+                K.pool_tokens_bwd(self.dhf, self.pool_arg, self.dh, self.B, n, d, cfg.pooling)
+            K.layernorm_bwd(self.dh, self.x_final, d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, d, False,
+                            self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), M, d)
         self.reducer.bucket_ready(0)
         # dz of the last block's MLP branch (afterwards every LayerNorm backward emits the next dz + its bias gradient)
         K.dropout_bwd(self.dx, self.dz, M, d, rate, key(rng.site_mlp(L - 1)))
@@ -515,6 +571,9 @@ class ViTEngine:
 
     def train_step(self, images_u8, labels, **opt):
         """augmented uint8 batch -> loss vector; runs forward, loss, backward, gradient exchange, AdamW."""
+        if not self.cfg.include_top:
+            raise ValueError("train_step needs the classification top (include_top=True); drive headless models with forward() + "
+                             "backward(doutput) + adamw_step()")
         self.forward(images_u8, training=True)
         loss = self.loss(labels)
         self.backward()

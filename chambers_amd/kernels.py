@@ -215,6 +215,37 @@ def dropout_bwd(dy, dz, m, n, drop_rate=0.0, drop_key=0):
     return dz
 
 
+POOL_MODES = {"avg": 0, "max": 1, "sum": 2}
+
+
+def pool_tokens(h, out, argmax, b, n, d, mode):
+    """pooling over the patch tokens 1..n-1 of h bf16 [b*n, d] (vision_transformer.py:172-181)."""
+    _lib.require_gpu(h, out)
+    _lib.call("chb_pool_tokens", _lib.ptr(h), _lib.ptr(out), _lib.ptr(argmax) if argmax is not None else None, int(b), int(n), int(d),
+              POOL_MODES[mode], _s())
+    return out
+
+
+def pool_tokens_bwd(dout, argmax, dh, b, n, d, mode):
+    _lib.require_gpu(dout, dh)
+    _lib.call("chb_pool_tokens_bwd", _lib.ptr(dout), _lib.ptr(argmax) if argmax is not None else None, _lib.ptr(dh), int(b), int(n), int(d),
+              POOL_MODES[mode], _s())
+    return dh
+
+
+def tanh_fwd(z, y_bf16=None):
+    """z fp32 (contiguous) -> tanh in place, optional bf16 copy."""
+    _lib.require_gpu(z)
+    _lib.call("chb_tanh_fwd", _lib.ptr(z), _lib.ptr(y_bf16) if y_bf16 is not None else None, z.numel(), _s())
+    return z
+
+
+def tanh_bwd(dy, y, dz_bf16):
+    _lib.require_gpu(dy, y, dz_bf16)
+    _lib.call("chb_tanh_bwd", _lib.ptr(dy), _lib.ptr(y), _lib.ptr(dz_bf16), dy.numel(), _s())
+    return dz_bf16
+
+
 def colsum(x, out, m=None):
     _lib.require_gpu(x, out)
     m = x.shape[0] if m is None else m

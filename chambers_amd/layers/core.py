@@ -66,7 +66,9 @@ class Dense(Layer):
         else:
             K.gemm_nt(a, self._cache.get(self, self.kernel), out, bias=self.bias.value)
             if act == "tanh":
-                out = torch.tanh(out)          # B x feature_dim head only (vision_transformer.py:275-278); not on the hot path
+                K.tanh_fwd(out)                # `feature` head (vision_transformer.py:275-278)
+            elif act == "softmax":
+                out = torch.softmax(out, dim=-1)   # classifier_activation of the stand-alone layer; training consumes logits
             elif act not in (None, "linear"):
                 raise ValueError("unsupported activation %r" % (act,))
         return out.reshape(*lead, self.units)

@@ -6,6 +6,7 @@ order (patch_embeddings/embedding, add_cls_token, pos_embedding, encoder[.layers
 predictions — cf. test_units/manual_test_vit_weights.py:79-155), so timm / Keras weight mappings carry over via
 get_weights()/set_weights().  Execution goes through the whole-model HIP engine (chambers_amd/engine.py).
 
+`pooling` ('cls' | 'avg' | 'max' | 'sum' | None), `feature_dim` (tanh head) and `include_top` follow :172-191,272-283.
 Not built here ("next"): DistilledVisionTransformer / DeiT zoo entries and the pretrained-weight
 download (`weights="imagenet21k+_224"` needs network + .h5); `weights` may be None or a path to an .npz of
 Keras-named arrays."""
@@ -143,8 +144,12 @@ class Model(Layer):
         if inputs.dtype != torch.uint8:
             from ... import kernels as K
             K.patchify_f32(inputs.to(torch.float32), self.cfg.patch_size, out=eng.patches)
-            return eng.forward(None, training=bool(training), prepatched=True).clone()
-        return eng.forward(inputs, training=bool(training)).clone()
+            out = eng.forward(None, training=bool(training), prepatched=True)
+        else:
+            out = eng.forward(inputs, training=bool(training))
+        if getattr(self, "classifier_activation", None) == "softmax":
+            return torch.softmax(out.float(), dim=-1)     # B x classes; training consumes logits (fused softmax-CE)
+        return out.clone()
 
     predict = call
 
@@ -168,11 +173,12 @@ def VisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, 
             raise ValueError("'weights' and 'feature_dim' are mutually exclusive.")
         raise RuntimeError("pretrained weights %r are downloaded from GitHub releases by the reference (vision_transformer.py:149-167); "
                            "this build has no network path — pass weights=None or a path to an .npz of Keras-named arrays" % (weights,))
-    if classifier_activation not in (None, "linear"):
-        raise ValueError("classifier_activation other than None is not on the hot path (logits feed the fused softmax-CE)")
+    if classifier_activation not in (None, "linear", "softmax"):
+        raise ValueError("classifier_activation must be None / 'linear' / 'softmax' (the loss kernel consumes logits); got %r"
+                         % (classifier_activation,))
     shape = _obtain_input_shape(input_tensor, input_shape, default_size=224, min_size=patch_size)
     cfg = E.ViTConfig(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate, image_size=shape[:2], classes=classes,
-                      include_top=include_top, feature_dim=feature_dim, pooling=pooling or "cls")
+                      include_top=include_top, feature_dim=feature_dim, pooling="none" if pooling is None else pooling)
     tn = initializers.TruncatedNormal(stddev=0.02)
     patch_embeddings = Sequential([Conv2D(filters=patch_dim, kernel_size=patch_size, strides=patch_size, padding="valid", name="embedding"),
                                    Reshape([-1, patch_dim])], name="patch_embeddings")
@@ -195,10 +201,11 @@ def VisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, 
         layers.append(f)
         feat_in = feature_dim
     if include_top:
-        head = Dense(units=classes, activation=classifier_activation, name="predictions")
+        head = Dense(units=classes, activation=None if classifier_activation == "linear" else classifier_activation, name="predictions")
         head.build((None, feat_in)); head.built = True
         layers.append(head)
     model = Model(cfg, layers, name=model_name)
+    model.classifier_activation = classifier_activation if include_top else None
     if weights is not None:
         if not os.path.exists(str(weights)):
             raise ValueError("weights file not found: %s" % (weights,))

@@ -160,8 +160,24 @@ int chb_colsum_bf16(const void* x, int64_t ld, float* out, int M, int N, void* s
  * loss_per_sample fp32 [B]; dlogits bf16 [B,ld_d] = (softmax - onehot) * grad_scale, pad cols 0. */
 int chb_softmax_ce(const float* logits, int64_t ld, const int32_t* labels, float* loss_per_sample, void* dlogits_bf16,
                    int64_t ld_d, int B, int classes, float grad_scale, void* stream);
-/* gather/scatter of the pooled cls rows: out bf16 [B,D] <- x bf16 rows b*N ; and
- * dx fp32 [B*N... ] handled by chb_layernorm_* strides. */
+/* pooling="cls" needs no kernel: chb_layernorm_* take the row stride N*D and touch the cls rows only.
+ * pooling="avg" | "max" | "sum" (vision_transformer.py:172-181: Cropping1D((1,0)) drops the cls token, then
+ * GlobalAveragePooling1D / GlobalMaxPooling1D / Sum over the remaining N-1 tokens):
+ * h bf16 [B,N,D] (final LayerNorm output) -> out bf16 [B,D] (fp32 reduction); mode CHB_POOL_*.
+ * argmax int32 [B,D] (token index of the first maximum) is written for CHB_POOL_MAX and may be NULL otherwise. */
+#define CHB_POOL_AVG 0
+#define CHB_POOL_MAX 1
+#define CHB_POOL_SUM 2
+int chb_pool_tokens(const void* h_bf16, void* out_bf16, int32_t* argmax, int B, int N, int D, int mode, void* stream);
+/* backward: dout bf16 [B,D] -> dh bf16 [B,N,D]; row 0 (cls) gets zeros; avg: dout/(N-1) on every token, sum: dout,
+ * max: dout on the argmax token of each (b, column), zero elsewhere (ties: first maximum). */
+int chb_pool_tokens_bwd(const void* dout_bf16, const int32_t* argmax, void* dh_bf16, int B, int N, int D, int mode,
+                        void* stream);
+/* Dense(feature_dim, activation="tanh", name="feature") (vision_transformer.py:275-278) around chb_gemm_nt:
+ * forward  y = tanh(z) in place on fp32 [n] plus a bf16 copy (operand of the next GEMM);
+ * backward dz bf16 [n] = dy * (1 - y*y), dy / y fp32. */
+int chb_tanh_fwd(float* z_inout, void* y_bf16, int64_t n, void* stream);
+int chb_tanh_bwd(const float* dy, const float* y, void* dz_bf16, int64_t n, void* stream);
 
 /* fp32 [R,C] -> bf16 [R,C] and/or bf16 [C,R] for a table of matrices (one launch). desc is a
  * device int64 array [n,4] = {src_offset, dst_offset, R, C} in elements; dst_t gets the

@@ -157,6 +157,8 @@ def vit_forward(p, images, cfg, keys=None, bf16=False, return_tokens=False):
     if return_tokens:
         return x
     pooling = cfg.get("pooling", "cls")
+    if pooling in ("avg", "max", "sum"):
+        x = _bf(x, bf16)     # the build pools the bf16 LayerNorm output (fp32 reduction)
     if pooling == "cls":
         x = x[:, 0, :]
     elif pooling == "avg":

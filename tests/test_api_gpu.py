@@ -102,3 +102,35 @@ def test_save_and_load_weights(tmp_path):
     m2 = VisionTransformer(16, 128, 1, 2, 256, input_shape=(32, 32, 3), weights=path, classes=5)
     for a, b in zip(m.get_weights(), m2.get_weights()):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("pooling,feature_dim,include_top", [("avg", 48, False), ("max", None, True), (None, None, False)])
+def test_model_builder_pooling_and_feature_head(pooling, feature_dim, include_top):
+    """Builder kwargs `pooling`, `feature_dim`, `include_top` (vision_transformer.py:194-210,272-283): output shape and values."""
+    from chambers_amd.models.backbones.vision_transformer import VisionTransformer
+    m = VisionTransformer(16, 128, 2, 2, 256, input_shape=(64, 48, 3), weights=None, classes=10, pooling=pooling,
+                          feature_dim=feature_dim, include_top=include_top)
+    _randomize(m, 7)
+    names = [l.name for l in m.layers]
+    assert ("feature" in names) == bool(feature_dim) and ("predictions" in names) == include_top
+    g = np.random.Generator(np.random.PCG64(1))
+    images = g.integers(0, 256, size=(3, 64, 48, 3), dtype=np.uint8)
+    out = m(torch.as_tensor(images, device="cuda")).float().cpu()
+    kw = {k: torch.tensor(v) for k, v in m.keras_weights().items()}
+    ref = vit_ref.vit_forward(kw, torch.from_numpy(A.imagenet_normalize(images, "tf")), m.cfg.as_oracle_cfg(), bf16=True,
+                              return_tokens=pooling is None)
+    expect = (3, 13, 128) if pooling is None else (3, 10 if include_top else (feature_dim or 128))
+    assert tuple(out.shape) == expect == tuple(ref.shape)
+    assert rel_l2(out, ref) < 4e-3
+
+
+def test_classifier_activation_softmax():
+    from chambers_amd.models.backbones.vision_transformer import VisionTransformer
+    m = VisionTransformer(16, 128, 1, 2, 256, input_shape=(32, 32, 3), weights=None, classes=5, classifier_activation="softmax")
+    m2 = VisionTransformer(16, 128, 1, 2, 256, input_shape=(32, 32, 3), weights=None, classes=5)
+    m2.set_weights(m.get_weights())
+    x = torch.randint(0, 256, (2, 32, 32, 3), dtype=torch.uint8, device="cuda")
+    pr, lg = m(x), m2(x)
+    assert torch.allclose(pr, torch.softmax(lg, dim=-1), atol=1e-6)
+    with pytest.raises(ValueError):
+        VisionTransformer(16, 128, 1, 2, 256, input_shape=(32, 32, 3), weights=None, classes=5, classifier_activation="relu6")

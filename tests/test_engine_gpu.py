@@ -155,6 +155,93 @@ def test_full_pipeline_with_randaugment_matches_oracle():
     assert rel_l2(logits, ref) < 2e-3
 
 
+def _grad_check(eng, kw, p, tol=3e-2):
+    grads = eng.export_keras_grads()
+    for k in kw:
+        if k.endswith("b_key"):
+            scale = float(torch.as_tensor(grads[k.replace("b_key", "w_key")]).abs().max())
+            assert float(np.abs(grads[k]).max()) < 2e-2 * scale, k
+            continue
+        r = rel_l2(grads[k], p[k].grad)
+        assert r < tol, "grad %s rel-l2 %g" % (k, r)
+
+
+@pytest.mark.parametrize("pooling,feature_dim,include_top", [("cls", 64, True), ("avg", None, True), ("max", 32, True), ("sum", None, True),
+                                                              ("avg", 64, False), ("max", None, False), ("cls", None, False),
+                                                              (None, None, False)])
+def test_pooling_modes_and_feature_head_match_oracle(pooling, feature_dim, include_top):
+    """vision_transformer.py:172-191 (_pool: cls / avg / max / sum after dropping the cls token; None = token sequence),
+    :275-283 (tanh `feature` head, `predictions` head); forward and every gradient against the oracle."""
+    cfg = _cfg(pooling="none" if pooling is None else pooling, feature_dim=feature_dim, include_top=include_top)
+    bsz, seed = 4, 5
+    eng, kw, images, labels = _setup(cfg, bsz, training=True, seed=seed)
+    assert ("feature/kernel" in kw) == bool(feature_dim) and ("predictions/kernel" in kw) == include_top
+    out = eng.forward(torch.as_tensor(images, device="cuda"), training=True).float()
+    x = torch.from_numpy(A.imagenet_normalize(images, "tf"))
+    p = _oracle_params(kw, requires_grad=True)
+    ref = vit_ref.vit_forward(p, x, cfg.as_oracle_cfg(), keys=_keys(cfg, seed, 0), bf16=True, return_tokens=pooling is None)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert rel_l2(out.cpu(), ref.detach()) < 4e-3, rel_l2(out.cpu(), ref.detach())
+    if include_top:
+        lab = torch.as_tensor(labels)
+        eng.loss(lab.cuda())
+        eng.backward()
+        torch.nn.functional.cross_entropy(ref, lab).backward()
+    else:
+        dout = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9))
+        eng.backward(dout.cuda())
+        ref.backward(dout)
+    _grad_check(eng, kw, p)
+
+
+def test_headless_model_rejects_train_step_and_bad_doutput():
+    cfg = _cfg(include_top=False)
+    eng, kw, images, labels = _setup(cfg, 2, training=True)
+    with pytest.raises(ValueError):
+        eng.train_step(torch.as_tensor(images, device="cuda"), torch.as_tensor(labels, device="cuda"))
+    eng.forward(torch.as_tensor(images, device="cuda"), training=True)
+    with pytest.raises(ValueError):
+        eng.backward()
+    with pytest.raises(ValueError):
+        eng.backward(torch.zeros(2, 7, device="cuda"))
+
+
+def test_vit_384_long_sequence_train_step_config5():
+    """BASELINE config 5 geometry: 384x384 input, patch 16 -> N = 577 tokens (two-pass attention backward); reduced width/depth
+    so the oracle finishes in seconds."""
+    cfg = _cfg(patch_dim=128, n_heads=2, ff_dim=256, n_encoder_layers=2, image_size=(384, 384), classes=10, dropout_rate=0.1)
+    assert cfg.n_tokens == 577
+    bsz, seed = 2, 11
+    eng, kw, images, labels = _setup(cfg, bsz, training=True, seed=seed)
+    lab = torch.as_tensor(labels)
+    logits = eng.forward(torch.as_tensor(images, device="cuda"), training=True)
+    eng.loss(lab.cuda())
+    eng.backward()
+    x = torch.from_numpy(A.imagenet_normalize(images, "tf"))
+    p = _oracle_params(kw, requires_grad=True)
+    ref = vit_ref.vit_forward(p, x, cfg.as_oracle_cfg(), keys=_keys(cfg, seed, 0), bf16=True)
+    torch.nn.functional.cross_entropy(ref, lab).backward()
+    assert rel_l2(logits.cpu(), ref.detach()) < 4e-3, rel_l2(logits.cpu(), ref.detach())
+    _grad_check(eng, kw, p)
+
+
+def test_vit_large_width_train_step_config4():
+    """BASELINE config 4 geometry: ViT-L/16 width (D 1024, 16 heads, ff 4096) at 224x224, depth cut to 2 blocks."""
+    cfg = _cfg(patch_dim=1024, n_heads=16, ff_dim=4096, n_encoder_layers=2, image_size=(224, 224), classes=1000, dropout_rate=0.1)
+    bsz, seed = 2, 13
+    eng, kw, images, labels = _setup(cfg, bsz, training=True, seed=seed)
+    lab = torch.as_tensor(labels)
+    logits = eng.forward(torch.as_tensor(images, device="cuda"), training=True)
+    eng.loss(lab.cuda())
+    eng.backward()
+    x = torch.from_numpy(A.imagenet_normalize(images, "tf"))
+    p = _oracle_params(kw, requires_grad=True)
+    ref = vit_ref.vit_forward(p, x, cfg.as_oracle_cfg(), keys=_keys(cfg, seed, 0), bf16=True)
+    torch.nn.functional.cross_entropy(ref, lab).backward()
+    assert rel_l2(logits.cpu(), ref.detach()) < 4e-3, rel_l2(logits.cpu(), ref.detach())
+    _grad_check(eng, kw, p)
+
+
 def test_vit_tiny_224_forward_config1():
     """BASELINE config 1: ViT-Ti/16 forward on 8x224x224x3 (the reference's CPU-runnable case)."""
     cfg = _cfg(patch_dim=192, n_heads=3, ff_dim=768, n_encoder_layers=12, image_size=(224, 224), classes=1000, dropout_rate=0.1)
