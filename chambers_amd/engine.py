@@ -117,6 +117,55 @@ def build_param_table(cfg, decay_fn=None):
     return specs, off, buckets
 
 
+def keras_variable_names(cfg):
+    """Internal tensor name -> the `var.name` strings of the Keras variables it holds, as the reference model would
+    name them (scope = nesting of layer names; un-named sublayers get Keras' per-class auto names in construction
+    order: EncoderLayer.__init__ builds multi_head_attention, norm1, dense1, dense2, norm2 — layers/transformer.py:31-49 —
+    and Encoder builds its layers, then the output norm, :271-283).  [UPSTREAM-RECALLED: Keras auto-naming.]
+    The optimizer's decay_include / decay_exclude regexes are matched against these (optimizers.py:169-181)."""
+    def auto(base, k):
+        return base if k == 0 else "%s_%d" % (base, k)
+
+    names = {"patch_embeddings/embedding/kernel": ["patch_embeddings/embedding/kernel:0"],
+             "patch_embeddings/embedding/bias": ["patch_embeddings/embedding/bias:0"],
+             "add_cls_token/embeddings": ["add_cls_token/embeddings:0"], "pos_embedding/embeddings": ["pos_embedding/embeddings:0"]}
+    L = cfg.n_encoder_layers
+    for i in range(L):
+        p = "encoder/layer_%d/" % i
+        scope = "encoder/%s/" % auto("encoder_layer", i)
+        mha = scope + auto("multi_head_attention", i) + "/"
+        names[p + "qkv/kernel"] = [mha + "w_query:0", mha + "w_key:0", mha + "w_value:0"]
+        names[p + "qkv/bias"] = [mha + "b_query:0", mha + "b_key:0", mha + "b_value:0"]
+        names[p + "proj/kernel"], names[p + "proj/bias"] = [mha + "w_projection:0"], [mha + "b_projection:0"]
+        for j, nm in enumerate(("norm1", "norm2")):
+            ln = scope + auto("layer_normalization", 2 * i + j) + "/"
+            names[p + nm + "/gamma"], names[p + nm + "/beta"] = [ln + "gamma:0"], [ln + "beta:0"]
+        for j, nm in enumerate(("dense1", "dense2")):
+            dn = scope + auto("dense", 2 * i + j) + "/"
+            names[p + nm + "/kernel"], names[p + nm + "/bias"] = [dn + "kernel:0"], [dn + "bias:0"]
+    ln = "encoder/" + auto("layer_normalization", 2 * L) + "/"
+    names["encoder/norm/gamma"], names["encoder/norm/beta"] = [ln + "gamma:0"], [ln + "beta:0"]
+    if cfg.feature_dim:
+        names["feature/kernel"], names["feature/bias"] = ["feature/kernel:0"], ["feature/bias:0"]
+    if cfg.include_top:
+        names["predictions/kernel"], names["predictions/bias"] = ["predictions/kernel:0"], ["predictions/bias:0"]
+    return names
+
+
+def decay_fn_from_variable_predicate(cfg, allowed):
+    """Lift a per-Keras-variable predicate (name -> bool) to the engine's tensors.  The fused QKV kernel / bias hold
+    three Keras variables; the decay flag is per tensor, so a predicate that separates them is refused."""
+    table = keras_variable_names(cfg)
+
+    def fn(internal_name):
+        votes = {bool(allowed(v)) for v in table[internal_name]}
+        if len(votes) != 1:
+            raise ValueError("weight-decay filter separates %s, which are stored as one fused tensor (%s)"
+                             % (", ".join(table[internal_name]), internal_name))
+        return votes.pop()
+    return fn
+
+
 # ---------------------------------------------------------------------------------------------
 # Keras-layout <-> internal-layout conversion (SURVEY §8b "weight naming / ownership")
 # ---------------------------------------------------------------------------------------------

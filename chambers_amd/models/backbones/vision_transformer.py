@@ -153,9 +153,28 @@ class Model(Layer):
 
     predict = call
 
+    def compile(self, optimizer=None, **unused):
+        """keras Model.compile for the part the hot path uses: a chambers_amd.optimizers.AdamW (hyper-parameters may be
+        schedules, e.g. chambers_amd.schedules.LinearWarmup; decay_include / decay_exclude select the decayed variables).
+        The loss is the fused sparse softmax cross-entropy from logits."""
+        self.optimizer = optimizer
+        self._engines = {k: v for k, v in self._engines.items() if not k[1]}   # training engines bake the decay flags in
+
     def train_step(self, images_u8, labels, **opt):
-        eng = self.engine(images_u8.shape[0], training=True)
-        loss = eng.train_step(images_u8, labels, **opt)
+        """One optimisation step on an (augmented) uint8 NHWC batch; returns the per-sample loss.  Uses the compiled
+        optimizer if there is one, else AdamW with the keyword hyper-parameters given here."""
+        optimizer = getattr(self, "optimizer", None)
+        if optimizer is None:
+            return self.engine(images_u8.shape[0], training=True).train_step(images_u8, labels, **opt)
+        if opt:
+            raise ValueError("hyper-parameters come from the compiled optimizer; got %s" % sorted(opt))
+        eng = self.engine(images_u8.shape[0], training=True, decay_fn=optimizer.decay_fn(self.cfg))
+        if not self.cfg.include_top:
+            raise ValueError("train_step needs the classification top (include_top=True)")
+        eng.forward(images_u8, training=True)
+        loss = eng.loss(labels)
+        eng.backward()
+        optimizer.apply(eng)
         return loss
 
     def sync_from_engine(self, batch_size):

@@ -26,11 +26,17 @@ class AdamW:
             return not any(re.search(n, var_name) is not None for n in self.decay_exclude)
         return True
 
-    def decay_fn(self):
-        """Predicate for chambers_amd.engine.build_param_table(decay_fn=...)."""
-        return self._is_decay_allowed
+    def decay_fn(self, cfg=None):
+        """Predicate for chambers_amd.engine.build_param_table(decay_fn=...) / ViTEngine(decay_fn=...).  With the model's
+        ViTConfig the regexes are matched against the reference's Keras variable names (`var.name`, optimizers.py:169-181)
+        via engine.keras_variable_names; without it, against the engine's own tensor names."""
+        if cfg is None:
+            return self._is_decay_allowed
+        from .engine import decay_fn_from_variable_predicate
+        return decay_fn_from_variable_predicate(cfg, self._is_decay_allowed)
 
     def _value(self, v, step):
+        """Hyper-parameters may be schedules (keras LearningRateSchedule semantics: called with `iterations`)."""
         return float(v(step)) if callable(v) else float(v)
 
     def apply(self, engine):

@@ -134,3 +134,31 @@ def test_classifier_activation_softmax():
     assert torch.allclose(pr, torch.softmax(lg, dim=-1), atol=1e-6)
     with pytest.raises(ValueError):
         VisionTransformer(16, 128, 1, 2, 256, input_shape=(32, 32, 3), weights=None, classes=5, classifier_activation="relu6")
+
+
+def test_compile_with_adamw_regex_and_warmup_schedule():
+    """Model.compile(optimizer=AdamW(decay_exclude=..., learning_rate=LinearWarmup(...))): excluded variables see no decay,
+    the step size follows the schedule (step 0 of a ramp has lr 0: only the decay moves the weights)."""
+    from chambers_amd.models.backbones.vision_transformer import VisionTransformer
+    from chambers_amd.optimizers import AdamW
+    from chambers_amd.schedules import LinearWarmup
+    m = VisionTransformer(16, 128, 1, 2, 256, input_shape=(32, 32, 3), weights=None, classes=5)
+    _randomize(m, 3)
+    before = {k: v.copy() for k, v in m.keras_weights().items()}
+    m.compile(optimizer=AdamW(0.1, decay_exclude=["bias", "/b_", "layer_normalization", "embeddings"], learning_rate=LinearWarmup(1e-3, 4)))
+    x = torch.randint(0, 256, (4, 32, 32, 3), dtype=torch.uint8, device="cuda")
+    y = torch.randint(0, 5, (4,), device="cuda")
+    m.train_step(x, y)
+    m.sync_from_engine(4)
+    after = m.keras_weights()
+    for k in before:
+        decayed = (k.endswith("kernel") or "/w_" in k) and "embeddings" not in k   # "patch_embeddings/..." matches the regex too
+        if decayed:
+            np.testing.assert_allclose(after[k], before[k] * np.float32(0.9), rtol=2e-6, atol=1e-9, err_msg=k)   # lr(0) = 0
+        else:
+            np.testing.assert_array_equal(after[k], before[k], err_msg=k)
+    with pytest.raises(ValueError):
+        m.train_step(x, y, learning_rate=1.0)
+    l1 = m.train_step(x, y)        # lr(1) = 2.5e-4 now moves everything
+    m.sync_from_engine(4)
+    assert not np.array_equal(m.keras_weights()["predictions/bias"], before["predictions/bias"]) and torch.isfinite(l1).all()

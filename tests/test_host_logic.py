@@ -115,6 +115,49 @@ def test_adamw_facade_regex_semantics():
     assert {s.name: s.decay for s in specs}["encoder/layer_0/qkv/kernel"] and not {s.name: s.decay for s in specs}["encoder/layer_0/qkv/bias"]
 
 
+def test_adamw_regex_on_keras_variable_names():
+    """decay_include / decay_exclude are matched on the reference's `var.name` strings (optimizers.py:169-181)."""
+    from chambers_amd.engine import ViTConfig, build_param_table, keras_variable_names
+    from chambers_amd.optimizers import AdamW
+    cfg = ViTConfig(16, 128, 2, 2, 256, image_size=(32, 32), classes=10, feature_dim=32)
+    names = keras_variable_names(cfg)
+    specs, _, _ = build_param_table(cfg)
+    assert set(names) == {s.name for s in specs}
+    assert names["encoder/layer_0/norm2/gamma"] == ["encoder/encoder_layer/layer_normalization_1/gamma:0"]
+    assert names["encoder/layer_1/dense1/kernel"] == ["encoder/encoder_layer_1/dense_2/kernel:0"]
+    assert names["encoder/norm/beta"] == ["encoder/layer_normalization_4/beta:0"]
+    assert names["encoder/layer_1/qkv/kernel"][0] == "encoder/encoder_layer_1/multi_head_attention_1/w_query:0"
+    o = AdamW(0.05, decay_exclude=["bias", "/b_", "layer_normalization", "embeddings"])
+    dec = {s.name: s.decay for s in build_param_table(cfg, o.decay_fn(cfg))[0]}
+    assert dec["encoder/layer_0/qkv/kernel"] and dec["encoder/layer_1/dense2/kernel"] and dec["feature/kernel"]
+    assert not dec["encoder/layer_0/qkv/bias"] and not dec["encoder/layer_0/proj/bias"] and not dec["encoder/norm/gamma"]
+    assert not dec["pos_embedding/embeddings"] and not dec["add_cls_token/embeddings"] and not dec["predictions/bias"]
+    # a filter that would split the fused QKV tensor is refused, not silently approximated
+    with pytest.raises(ValueError):
+        build_param_table(cfg, AdamW(0.05, decay_include=["w_query"]).decay_fn(cfg))
+
+
+def test_linear_warmup_schedule():
+    """schedules.py:5-48: ramp (step * lr0/warmup, then the inner schedule shifted by warmup) and multiplier modes."""
+    from chambers_amd.schedules import LearningRateSchedule, LinearWarmup
+    s = LinearWarmup(1e-3, 10)
+    assert float(s(0)) == 0.0 and np.isclose(float(s(5)), 5e-4, rtol=1e-6) and float(s(10)) == np.float32(1e-3) == float(s(1000))
+    m = LinearWarmup(2e-3, 4, ramp=False)
+    assert np.isclose(float(m(1)), 5e-4, rtol=1e-6) and float(m(4)) == np.float32(2e-3) == float(m(9))
+
+    class Halving(LearningRateSchedule):
+        def __call__(self, step):
+            return np.float32(1e-2) * np.float32(0.5) ** np.float32(step)
+    r = LinearWarmup(Halving(), 2)
+    assert np.isclose(float(r(1)), 5e-3) and np.isclose(float(r(2)), 1e-2) and np.isclose(float(r(4)), 2.5e-3)
+    c = LinearWarmup(lambda: 4e-3, 2, ramp=False)
+    assert np.isclose(float(c(1)), 2e-3) and np.isclose(float(c(3)), 4e-3)
+    assert set(s.get_config()) == {"learning_rate", "warmup_steps", "ramp"}
+    # drives the optimizer facade: hyper-parameters that are schedules are evaluated at the optimizer step count
+    from chambers_amd.optimizers import AdamW
+    assert np.isclose(AdamW(0.0, learning_rate=s)._value(s, 5), 5e-4, rtol=1e-6)
+
+
 def test_rng_contract_matches_oracle_definition():
     from chambers_amd import rng
     for seed, step, site in ((0, 0, 0), (7, 3, 11), (2 ** 40 + 5, 1000, 36)):
