@@ -7,7 +7,8 @@
 //             accumulators (k-order permuted on both operands), V^T via ds_read_b64_tr_b16.
 //   backward: each of 8 waves owns 1/8 of the key tiles and keeps dK^T/dV^T for them in registers
 //             across all query blocks; dS goes once through LDS for dQ.  No atomics.  N > 224 takes
-//             the two-pass kernels further down (dK/dV per key chunk, dQ per query chunk).
+//             the two-pass kernels further down (dK/dV per key chunk, dQ per query chunk), and the
+//             streaming forward with online softmax.
 // Dropout on the probabilities uses the counter hash of common.hpp, element index
 // ((b*H + h)*N + q)*N + k, so forward and backward regenerate the same mask.
 //
@@ -67,7 +68,7 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64
 
 // ------------------------------------------------------------------------------------ forward
 template <int NTP, bool DROP>  // pairs of 16-key tiles; padded key count = 32 * NTP
-__global__ void __launch_bounds__(256, NTP <= 7 ? 2 : 1) attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse_out,
+__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse_out,
                                                        int N, int H, float scale_log2, float drop_scale, uint32_t drop_thr,
                                                        uint32_t drop_key) {
     constexpr int NKP = 32 * NTP, NT = 2 * NTP;
@@ -434,6 +435,144 @@ __device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
     return d;
 }
 
+// ------------------------------------------------------------------------------------ forward, long sequences
+// N > 224: the score row of a query no longer fits the register file next to K/V in LDS.  Workgroup = (head, 128
+// queries), a wave owns 16 queries; K / V stream through a double-buffered LDS chunk of 64 keys and the softmax is
+// computed online (running max / sum per query, accumulator rescaled when the max moves).  Same dropout element
+// index and the same operand rounding points as the resident kernel (un-normalised P rounded to bf16, 1/sum and
+// 1/(1-rate) applied to the fp32 output), so the two agree to bf16 rounding of P.
+template <bool DROP>
+__global__ void __launch_bounds__(512, 2) attn_fwd_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                              float* __restrict__ lse_out, int N, int H, float scale_log2,
+                                                              float drop_scale, uint32_t drop_thr, uint32_t drop_key) {
+    constexpr int KC = 64;
+    __shared__ __attribute__((aligned(16))) bf16_t Kb[2][KC * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vb[2][KC * HD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const bf16_t* base = qkv + (int64_t)b * N * D3 + h * HD;
+
+    const int q0w = 128 * blockIdx.y + 16 * wave;
+    const int q = q0w + i, qc = min(q, N - 1);
+    const bool wave_live = q0w < N;   // wave-uniform
+    const bf16_t* qp = base + (int64_t)qc * D3;
+    const bf16x8_t qf0 = *reinterpret_cast<const bf16x8_t*>(qp + g * 8);
+    const bf16x8_t qf1 = *reinterpret_cast<const bf16x8_t*>(qp + 32 + g * 8);
+    const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)N;
+
+    float m_run = -INFINITY;   // running max of the raw scores of this query (identical in the 4 lanes g of a query)
+    float l_run = 0.f;         // this lane's share of the running sum (keys 4g+r of every tile)
+    float4_t oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int sr = tid >> 3, sc = tid & 7;   // staging: 64 rows x 8 chunks, K and V
+    uint4 skv = make_uint4(0, 0, 0, 0), svv = make_uint4(0, 0, 0, 0);
+    auto stage_load = [&](int k0) {
+        const int r = k0 + sr;
+        skv = make_uint4(0, 0, 0, 0);
+        svv = make_uint4(0, 0, 0, 0);
+        if (r < N) {
+            const bf16_t* kp = base + (int64_t)r * D3 + Dm + sc * 8;
+            skv = *reinterpret_cast<const uint4*>(kp);
+            svv = *reinterpret_cast<const uint4*>(kp + Dm);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        *reinterpret_cast<uint4*>(Kb[buf] + sr * HD + ((sc ^ swz_row(sr)) << 3)) = skv;
+        *reinterpret_cast<uint4*>(Vb[buf] + sr * HD + ((sc ^ swz_trv(sr)) << 3)) = svv;
+    };
+
+    const int nkc = (N + KC - 1) / KC;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int cur = kc & 1, k0 = KC * kc;
+        if (kc + 1 < nkc) stage_load(k0 + KC);
+        if (wave_live) {
+            const bf16_t* Ks = Kb[cur];
+            const bf16_t* Vs = Vb[cur];
+            // S^T tiles of the chunk: lane (g,i) reg r = score(query i, key k0 + 16t + 4g + r)
+            float4_t s[KC / 16];
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < KC / 16; ++t) {
+                s[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                if (k0 + 16 * t < N) {   // wave-uniform
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, g), qf0, s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 + g), qf1, s[t], 0, 0, 0);
+                    if (k0 + 16 * t + 16 > N) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[t][r] = (k0 + 16 * t + 4 * g + r < N) ? s[t][r] : -INFINITY;
+                    }
+                } else {
+                    s[t] = (float4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                }
+                cmax = fmaxf(cmax, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+            }
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+            const float m_new = fmaxf(m_run, cmax);           // finite: every chunk holds at least one valid key
+            const float corr = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);   // first chunk: exp2(-inf) = 0
+            m_run = m_new;
+            const float mxs = m_new * scale_log2;
+            l_run *= corr;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] *= corr;
+#pragma unroll
+            for (int t = 0; t < KC / 16; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], scale_log2, -mxs));
+                    l_run += s[t][r];
+                }
+                if (DROP) {
+                    float keepc[4];
+                    keep4(ebase + (uint32_t)(k0 + 16 * t + 4 * g), drop_key, drop_thr, 1.0f, keepc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[t][r] *= keepc[r];
+                }
+            }
+            // O^T[d][q] += V^T[d][key] P^T[key][q]; k-slot (g, j): j<4 -> key 32u+4g+j, j>=4 -> key 32u+16+4g+(j-4)
+#pragma unroll
+            for (int u = 0; u < KC / 32; ++u) {
+                if (k0 + 32 * u < N) {   // wave-uniform
+                    const bf16x8_t pf = pack8(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8_t vf = lds_tr_frag<true>(Vs, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, i);
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kc + 1 < nkc) stage_store(cur ^ 1);
+        __syncthreads();
+    }
+    if (wave_live) {
+        float sum = l_run;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float oscale = (DROP ? drop_scale : 1.0f) / sum;
+        if (q < N) {
+            if (g == 0) lse_out[(int64_t)bh * N + q] = (m_run * scale_log2 + log2f(sum)) * 0.69314718055994530942f;
+            bf16_t* op = o + ((int64_t)b * N + q) * Dm + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 w;
+                w.x = pack_bf16x2(oacc[dt][0] * oscale, oacc[dt][1] * oscale);
+                w.y = pack_bf16x2(oacc[dt][2] * oscale, oacc[dt][3] * oscale);
+                *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
+            }
+        }
+    }
+}
+
 template <bool DROP>
 __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                            const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
@@ -735,7 +874,7 @@ extern "C" {
 int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate, uint32_t drop_key,
                       void* stream) {
     if (!qkv || !o || !lse || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
-    if (hd != HD || N > 608) return CHB_EUNSUPPORTED;
+    if (hd != HD) return CHB_EUNSUPPORTED;
     if ((double)B * H * N * N >= 4294967296.0) return CHB_EUNSUPPORTED;   // dropout element index is 32-bit
     if (B == 0) return CHB_OK;
     const float scale_log2 = 1.44269504088896340736f / sqrtf((float)hd);
@@ -745,6 +884,18 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* in = (const bf16_t*)qkv;
     bf16_t* out = (bf16_t*)o;
+    // Short sequences (N <= 128): K / V of the head resident in LDS, whole score row in registers.  Otherwise the streaming
+    // kernel with online softmax (any N; at N = 197 it runs 4 waves per SIMD against 2 and measures ~10 % faster).
+    // CHB_ATTN_FWD_ALGO = 1 | 2 forces resident (N <= 224) | streaming; the parity tests cross-check the two.
+    const char* algo_env = getenv("CHB_ATTN_FWD_ALGO");
+    const int algo = algo_env ? atoi(algo_env) : 0;
+    if (N > 224 || algo == 2 || (algo != 1 && N > 128)) {
+        const dim3 grid2(B * H, (N + 127) / 128);
+        if (thr) hipLaunchKernelGGL((attn_fwd_stream_kernel<true>), grid2, dim3(512), 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key);
+        else hipLaunchKernelGGL((attn_fwd_stream_kernel<false>), grid2, dim3(512), 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key);
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
 #define CHB_FWD(NTP)                                                                                                      \
     do {                                                                                                                  \
         if (thr) hipLaunchKernelGGL((attn_fwd_kernel<NTP, true>), grid, block, 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key); \
@@ -753,9 +904,7 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
     if (N <= 32) CHB_FWD(1);
     else if (N <= 64) CHB_FWD(2);
     else if (N <= 128) CHB_FWD(4);
-    else if (N <= 224) CHB_FWD(7);
-    else if (N <= 416) CHB_FWD(13);
-    else CHB_FWD(19);
+    else CHB_FWD(7);
 #undef CHB_FWD
     CHB_LAUNCH_CHECK();
     return CHB_OK;

@@ -276,7 +276,7 @@ def _attn_ref(qkv, bsz, n, h, rate, key):
 
 @pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.0), (2, 197, 3, 0.1), (3, 17, 2, 0.1), (1, 64, 1, 0.0), (2, 33, 4, 0.5),
                                           (1, 128, 2, 0.1), (1, 577, 2, 0.1), (1, 1, 1, 0.0), (2, 224, 1, 0.1), (2, 225, 2, 0.1),
-                                          (1, 577, 3, 0.0), (1, 608, 1, 0.1), (2, 257, 1, 0.25)])
+                                          (1, 577, 3, 0.0), (1, 608, 1, 0.1), (2, 257, 1, 0.25), (1, 785, 1, 0.1)])
 def test_attention_fwd_bwd(bsz, n, h, rate):
     from chambers_amd import kernels as K
     d = h * 64
@@ -330,6 +330,27 @@ def test_attention_bwd_two_pass_matches_one_pass(bsz, n, h, rate, monkeypatch):
     assert torch.equal(g1[:, d:], g2[:, d:])                          # dK, dV
     assert rel_l2(g2[:, :d], g1[:, :d]) < 3e-3                        # dQ: one bf16 rounding of differently ordered fp32 sums
     assert rel_l2(b2[:d], b1[:d]) < 1e-4 and rel_l2(b2[2 * d:], b1[2 * d:]) < 1e-4
+
+
+@pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.1), (1, 224, 2, 0.0), (3, 50, 1, 0.1), (1, 1, 1, 0.0), (2, 130, 2, 0.5)])
+def test_attention_fwd_streaming_matches_resident(bsz, n, h, rate, monkeypatch):
+    """The long-sequence forward (online softmax over 64-key chunks) forced onto short inputs agrees with the LDS-resident
+    kernel: same dropout mask, log-sum-exp to fp32 rounding, output to the bf16 rounding of the un-normalised probabilities."""
+    from chambers_amd import kernels as K
+    d = h * 64
+    qkv = bf(torch.randn(bsz * n, 3 * d, generator=g(45)) * 1.5).cuda()
+    outs = []
+    for algo in ("1", "2"):
+        monkeypatch.setenv("CHB_ATTN_FWD_ALGO", algo)
+        o = torch.empty(bsz * n, d, dtype=torch.bfloat16, device="cuda")
+        lse = torch.empty(bsz * h * n, dtype=torch.float32, device="cuda")
+        K.attention_fwd(qkv, o, lse, bsz, n, h, 64, rate, 0x51ced)
+        torch.cuda.synchronize()
+        outs.append((o.float().cpu(), lse.cpu()))
+    (o1, l1), (o2, l2) = outs
+    assert torch.allclose(l1, l2, rtol=1e-6, atol=1e-5)
+    assert rel_l2(o2, o1) < 4e-3
+    assert torch.equal(o1 == 0, o2 == 0) or rate == 0.0   # identical keep mask (an all-dropped row is zero in both)
 
 
 def test_attention_fwd_fp32_probabilities_tolerance():

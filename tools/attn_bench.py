@@ -24,8 +24,13 @@ def t(fn, it=10):
 
 fl = 4.0 * B * H * N * N * 64
 for rate in (0.0, 0.1):
-    f = t(lambda: K.attention_fwd(qkv, o, lse, B, N, H, 64, rate, 7))
-    line = "B %d N %d H %d rate %.1f  fwd %.3f ms (%.0f TF/s)" % (B, N, H, rate, f, fl / f / 1e9)
+    line = "B %d N %d H %d rate %.1f " % (B, N, H, rate)
+    for algo in ("1", "2"):
+        if algo == "1" and N > 224:
+            continue
+        os.environ["CHB_ATTN_FWD_ALGO"] = algo
+        f = t(lambda: K.attention_fwd(qkv, o, lse, B, N, H, 64, rate, 7))
+        line += "   fwd[%s] %.3f ms (%.0f TF/s)" % ("resident" if algo == "1" else "stream", f, fl / f / 1e9)
     for algo in ("1", "2"):
         if algo == "1" and N > 224:
             continue
