@@ -226,6 +226,64 @@ __global__ void __launch_bounds__(256) affine_kernel(const uint8_t* __restrict__
     }
 }
 
+// Fast path for what the augmentation schemes launch (one affine transform for the whole batch, projective row = 0, RGB,
+// W % 4 == 0): no division, no per-pixel branch.  A wave owns 4 consecutive output rows, a lane 4 pixels of each; the per-row
+// terms a1*y, b1*y are formed once (same fp32 operation order as the generic kernel: (a0*x + a1*y) + a2), every source pixel
+// is one unaligned dword load from a clamped address, and `fill` is selected afterwards.
+__global__ void __launch_bounds__(256) affine_rgb_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
+                                                         int W, float a0, float a1, float a2, float b0, float b1, float b2, int fill) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wq = W >> 2;
+    const int rows = B * H;
+    const int64_t img_bytes = (int64_t)H * W * 3;
+    const uint32_t fillw = ((uint32_t)fill) * 0x01010101u;
+    const float fW = (float)W, fH = (float)H;
+    for (int row0 = (blockIdx.x * 4 + wave) * 4; row0 < rows; row0 += gridDim.x * 16) {
+        for (int xq = lane; xq < wq; xq += 64) {
+            const int x0 = xq * 4;
+            float fx[4], ax[4], bx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fx[i] = (float)(x0 + i);
+                ax[i] = a0 * fx[i];
+                bx[i] = b0 * fx[i];
+            }
+            uint32_t w[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rr = min(row0 + k, rows - 1);   // wave-uniform
+                const int n = rr / H, oy = rr - n * H;
+                const uint8_t* img = in + (int64_t)n * img_bytes;
+                const bool last_img = n == B - 1;
+                const float fy = (float)oy;
+                const float ay = a1 * fy, by = b1 * fy;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float ix = (ax[i] + ay) + a2;
+                    const float iy = (bx[i] + by) + b2;
+                    const float rx = roundf(ix), ry = roundf(iy);  // half away from zero
+                    const bool ok = (rx >= 0.0f) && (rx < fW) && (ry >= 0.0f) && (ry < fH);
+                    const int off = ok ? ((int)ry * W + (int)rx) * 3 : 0;
+                    // the dword at the very last pixel of the batch would end one byte past the buffer: step back and shift
+                    const int over = (last_img && (int64_t)off + 4 > img_bytes) ? 1 : 0;
+                    const uint32_t v = reinterpret_cast<const u32_unaligned*>(img + off - over)->v >> (8 * over);
+                    w[k][i] = ok ? v : fillw;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (row0 + k >= rows) break;
+                uint8_t b[12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    b[3 * i + 0] = w[k][i] & 0xff; b[3 * i + 1] = (w[k][i] >> 8) & 0xff; b[3 * i + 2] = (w[k][i] >> 16) & 0xff;
+                }
+                *reinterpret_cast<px4_t*>(out + (int64_t)(row0 + k) * W * 3 + (int64_t)x0 * 3) = pack12(b);
+            }
+        }
+    }
+}
+
 // ---- cutout (tfa.image.random_cutout with explicit centres), :495-499 -------------
 // One wave per 4 consecutive image rows (4 independent 12-byte loads in flight per lane, no per-thread division).
 __global__ void __launch_bounds__(256) cutout_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
@@ -564,6 +622,96 @@ __global__ void __launch_bounds__(256) sharpness_kernel(const uint8_t* __restric
     }
 }
 
+// Fast path (C == 3, W % 4 == 0): one wave per PAIR of output rows.  A lane owns the same 4-pixel quad in both rows; the four
+// input rows it needs arrive as aligned 12-byte loads (one per row), the left / right halo pixel comes from the neighbouring
+// lane's registers (a direct dword load only where the 64-lane window ends inside the row).  Every input byte is converted and
+// multiplied by 1/13 once and reused by up to six outputs; the per-output sum keeps the oracle's row-major order, so the result
+// is bit-identical to the generic kernel.
+template <int MODE>
+__global__ void __launch_bounds__(256) sharpness_rows_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
+                                                             int W, float factor) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wq = W >> 2;
+    const int hp = (H + 1) >> 1;                 // row pairs per image
+    const int pairs = B * hp;
+    const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+    const int64_t row_bytes = (int64_t)W * 3;
+    for (int pr = blockIdx.x * 4 + wave; pr < pairs; pr += gridDim.x * 4) {
+        const int n = pr / hp, y0 = (pr - n * hp) * 2;          // output rows y0, y0 + 1 of image n
+        const uint8_t* img = in + (int64_t)n * H * row_bytes;
+        uint8_t* oimg = out + (int64_t)n * H * row_bytes;
+        for (int xb = 0; xb < wq; xb += 64) {
+            const int xq = xb + lane;
+            const bool live = xq < wq;
+            const int x0 = xq * 4;
+            // input rows y0-1 .. y0+2 (rows outside the image are never used: border rows keep the original)
+            float p1[4][18];     // (float)byte * k1 for [left px | own 4 px | right px]
+            uint32_t own[2][3];  // the original bytes of the two output rows
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int yy = y0 - 1 + r;
+                const bool rin = (yy >= 0) && (yy < H);
+                px4_t v;
+                v.w[0] = v.w[1] = v.w[2] = 0;
+                const uint8_t* rp = img + (int64_t)(rin ? yy : 0) * row_bytes;
+                if (rin && live) v = *reinterpret_cast<const px4_t*>(rp + (int64_t)x0 * 3);
+                uint32_t lft = __shfl_up(v.w[2], 1, 64), rgt = __shfl_down(v.w[0], 1, 64);
+                if (rin && live && lane == 0 && xq > 0) lft = *reinterpret_cast<const uint32_t*>(rp + (int64_t)x0 * 3 - 4);
+                if (rin && live && lane == 63 && xq + 1 < wq) rgt = *reinterpret_cast<const uint32_t*>(rp + (int64_t)x0 * 3 + 12);
+                if (r == 1 || r == 2) { own[r - 1][0] = v.w[0]; own[r - 1][1] = v.w[1]; own[r - 1][2] = v.w[2]; }
+                p1[r][0] = (float)((lft >> 8) & 0xff) * k1;
+                p1[r][1] = (float)((lft >> 16) & 0xff) * k1;
+                p1[r][2] = (float)(lft >> 24) * k1;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    p1[r][3 + 4 * k + 0] = (float)(v.w[k] & 0xff) * k1;
+                    p1[r][3 + 4 * k + 1] = (float)((v.w[k] >> 8) & 0xff) * k1;
+                    p1[r][3 + 4 * k + 2] = (float)((v.w[k] >> 16) & 0xff) * k1;
+                    p1[r][3 + 4 * k + 3] = (float)(v.w[k] >> 24) * k1;
+                }
+                p1[r][15] = (float)(rgt & 0xff) * k1;
+                p1[r][16] = (float)((rgt >> 8) & 0xff) * k1;
+                p1[r][17] = (float)((rgt >> 16) & 0xff) * k1;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = y0 + j;
+                if (y >= H || !live) continue;
+                const bool yin = (y >= 1) && (y < H - 1);
+                uint8_t ob[12];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    ob[4 * k + 0] = own[j][k] & 0xff; ob[4 * k + 1] = (own[j][k] >> 8) & 0xff;
+                    ob[4 * k + 2] = (own[j][k] >> 16) & 0xff; ob[4 * k + 3] = own[j][k] >> 24;
+                }
+                uint8_t b[12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int x = x0 + i;
+                    const bool interior = yin && (x >= 1) && (x < W - 1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint8_t orig = ob[3 * i + c];
+                        // window column (i + kx) of p1 is pixel x - 1 + kx; rows j, j+1, j+2 are y-1, y, y+1
+                        float acc = p1[j][3 * i + c];
+                        acc = acc + p1[j][3 * (i + 1) + c];
+                        acc = acc + p1[j][3 * (i + 2) + c];
+                        acc = acc + p1[j + 1][3 * i + c];
+                        acc = acc + (float)orig * k5;
+                        acc = acc + p1[j + 1][3 * (i + 2) + c];
+                        acc = acc + p1[j + 2][3 * i + c];
+                        acc = acc + p1[j + 2][3 * (i + 1) + c];
+                        acc = acc + p1[j + 2][3 * (i + 2) + c];
+                        const uint8_t deg = interior ? trunc_u8(acc) : orig;
+                        b[3 * i + c] = sharp_finish<MODE>(deg, orig, factor);
+                    }
+                }
+                *reinterpret_cast<px4_t*>(oimg + (int64_t)y * row_bytes + (int64_t)x0 * 3) = pack12(b);
+            }
+        }
+    }
+}
+
 // ---- ImageNetNormalization, :629-682 ---------------------------------------------------
 struct NormConst { float mean[3]; float stdv[3]; };
 
@@ -599,28 +747,38 @@ __global__ void __launch_bounds__(256) normalize_kernel(const TIN* __restrict__ 
     }
 }
 
-// mode "tf" for any channel count (elementwise), 12 bytes -> 12 floats per thread
-__global__ void __launch_bounds__(256) normalize_tf_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n_groups,
-                                                              int64_t n_bytes) {
-    const px4_t* in4 = reinterpret_cast<const px4_t*>(in);
+// modes "tf" and "torch" are elementwise given the channel of each byte: a lane converts one aligned dword (4 consecutive
+// bytes) into one float4, so every wave-level load is 256 contiguous bytes and every store 1 KiB contiguous.
+template <int MODE>
+__global__ void __launch_bounds__(256) normalize_u8x4_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n_quads,
+                                                             int64_t n_bytes, int C, NormConst nc) {
+    const uint32_t* in4 = reinterpret_cast<const uint32_t*>(in);
     float4* out4 = reinterpret_cast<float4*>(out);
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x) {
-        uint8_t b[12];
-        unpack12(in4[g], b);
-        float f[12];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < n_quads; q0 += 4 * stride) {
+        uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            float v = (float)b[i] / 127.5f;
-            f[i] = v - 1.0f;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = q0 + u * stride;
+            w[u] = q < n_quads ? in4[q] : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) out4[g * 3 + i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = q0 + u * stride;
+            if (q >= n_quads) break;
+            const int c0 = MODE == 1 ? 0 : (int)((q * 4) % C);
+            float f[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int c = c0 + k;
+                if (MODE != 1) c = c >= C ? c - C : c, c = c >= C ? c - C : c;   // C == 3 here: at most two wraps
+                f[k] = norm1<MODE>((uint8_t)(w[u] >> (8 * k)), c, nc);
+            }
+            out4[q] = make_float4(f[0], f[1], f[2], f[3]);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int64_t i = n_groups * 12; i < n_bytes; ++i) {
-            float v = (float)in[i] / 127.5f;
-            out[i] = v - 1.0f;
-        }
+        for (int64_t e = n_quads * 4; e < n_bytes; ++e) out[e] = norm1<MODE>(in[e], (int)(e % C), nc);
 }
 
 // Normalise (mode tf/torch/caffe) + patchify: uint8 NHWC -> bf16 [B*gh*gw, p*p*3] rows, the
@@ -726,6 +884,13 @@ int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, 
     if (!transform_host8 && !transforms_dev) return CHB_EINVAL;
     float t[8] = {1, 0, 0, 0, 1, 0, 0, 0};
     if (transform_host8) for (int i = 0; i < 8; ++i) t[i] = transform_host8[i];
+    if (transform_host8 && t[6] == 0.0f && t[7] == 0.0f && C == 3 && (W & 3) == 0 && !((uintptr_t)out & 3) &&
+        (int64_t)H * W * 3 < 2147483647LL) {
+        hipLaunchKernelGGL(affine_rgb_kernel, dim3(row_grid(((int64_t)B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
+                           t[0], t[1], t[2], t[3], t[4], t[5], fill & 0xff);
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
     hipLaunchKernelGGL(affine_kernel, dim3(row_grid(((int64_t)B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
                        transform_host8 ? nullptr : transforms_dev, per_image, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
                        fill & 0xff);
@@ -783,8 +948,16 @@ int chb_aug_equalize(const uint8_t* in, uint8_t* out, int B, int H, int W, int C
 int chb_aug_sharpness(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, float factor, void* stream) {
     if (B == 0) return CHB_OK;
     if (!in || !out || B < 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return CHB_EINVAL;
-    const int grid = row_grid((int64_t)B * H);
     hipStream_t s = (hipStream_t)stream;
+    if (C == 3 && (W & 3) == 0 && !((uintptr_t)in & 3) && !((uintptr_t)out & 3)) {
+        const int grid2 = row_grid((int64_t)B * ((H + 1) / 2));
+        if (factor == 0.0f) hipLaunchKernelGGL(sharpness_rows_kernel<0>, dim3(grid2), dim3(256), 0, s, in, out, B, H, W, factor);
+        else if (factor > 0.0f && factor < 1.0f) hipLaunchKernelGGL(sharpness_rows_kernel<1>, dim3(grid2), dim3(256), 0, s, in, out, B, H, W, factor);
+        else hipLaunchKernelGGL(sharpness_rows_kernel<2>, dim3(grid2), dim3(256), 0, s, in, out, B, H, W, factor);
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
+    const int grid = row_grid((int64_t)B * H);
     if (factor == 0.0f) hipLaunchKernelGGL(sharpness_kernel<0>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C, factor);
     else if (factor > 0.0f && factor < 1.0f) hipLaunchKernelGGL(sharpness_kernel<1>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C, factor);
     else hipLaunchKernelGGL(sharpness_kernel<2>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C, factor);
@@ -796,16 +969,18 @@ int chb_normalize_u8(const uint8_t* in, float* out, int64_t n_pixels, int channe
     if (n_pixels == 0) return CHB_OK;
     if (!in || !out || n_pixels < 0 || channels <= 0) return CHB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    const int64_t nb = n_pixels * channels;
+    const bool aligned = !((uintptr_t)in & 3) && !((uintptr_t)out & 15);
     if (mode == CHB_NORM_TF) {
-        const int64_t nb = n_pixels * channels;
-        if (((uintptr_t)in & 3) || ((uintptr_t)out & 15)) return CHB_EINVAL;
-        hipLaunchKernelGGL(normalize_tf_u8_kernel, dim3(stream_grid(nb / 12)), dim3(256), 0, s, in, out, nb / 12, nb);
+        if (!aligned) return CHB_EINVAL;
+        hipLaunchKernelGGL(normalize_u8x4_kernel<1>, dim3(stream_grid((nb / 4 + 3) / 4)), dim3(256), 0, s, in, out, nb / 4, nb, channels, kTorch);
     } else if (channels != 3) {
         return CHB_EINVAL;  // caffe/torch carry 3-channel constants (:649,:656)
     } else if (mode == CHB_NORM_CAFFE) {
         hipLaunchKernelGGL((normalize_kernel<0, uint8_t>), dim3(stream_grid(n_pixels)), dim3(256), 0, s, in, out, n_pixels, kCaffe);
     } else if (mode == CHB_NORM_TORCH) {
-        hipLaunchKernelGGL((normalize_kernel<2, uint8_t>), dim3(stream_grid(n_pixels)), dim3(256), 0, s, in, out, n_pixels, kTorch);
+        if (aligned) hipLaunchKernelGGL(normalize_u8x4_kernel<2>, dim3(stream_grid((nb / 4 + 3) / 4)), dim3(256), 0, s, in, out, nb / 4, nb, 3, kTorch);
+        else hipLaunchKernelGGL((normalize_kernel<2, uint8_t>), dim3(stream_grid(n_pixels)), dim3(256), 0, s, in, out, n_pixels, kTorch);
     } else {
         return CHB_EINVAL;
     }
