@@ -134,6 +134,20 @@ def cpu_baseline(cfg_kwargs, sample_images=8, steps=2):
             "sample": "%d images x %d timed steps (1 warm-up) of the same train step, fp32 torch-CPU oracle" % (sample_images, steps)}
 
 
+def pmc_traffic(kernel):
+    """Per-launch HBM bytes of `kernel` from the newest profiles/*bench_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_bench.sh); None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*bench_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        k = json.load(f).get("kernels", {}).get(kernel)
+    if not k:
+        return None
+    return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": "profiles/" + os.path.basename(files[-1])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +248,12 @@ def main():
                             "total_ms": round(v["total_ms"], 2)} for k, v in ks.items()},
             "final_loss": final_loss,
         }
+        # HBM-side bytes per launch of the dominant kernel: PMC counters need their own rocprofv3 passes (tools/pmc_bench.sh runs
+        # them over this same command); the committed summary is quoted here when it was taken on this workload
+        tr = pmc_traffic(dom) if (args.model == "vitb16" and args.batch == 512 and args.image_size == 224) else None
+        if tr is not None:
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg_kwargs)
         else:

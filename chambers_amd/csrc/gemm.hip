@@ -34,6 +34,7 @@ struct GemmParams {
     float drop_scale; uint32_t drop_thr; uint32_t drop_key;
     int tiles_m, tiles_n;
     float* colsum;   // optional fp32 [N]: += column sums of the output (bias gradient of the consumer layer)
+    int walk_panel;  // persistent 256x256 kernel: XCD-panel tile walk (see TileWalk)
 };
 
 // bijective XCD-aware remap: consecutive virtual ids (which share an A panel) stay on one XCD
@@ -325,6 +326,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
                 }
                 csum[0] += v[0]; csum[1] += v[1]; csum[2] += v[2]; csum[3] += v[3];
             }
+            // keep the erf polynomial of one 4-element group from being interleaved with the next three: the wider schedule
+            // needs more than the 256 registers a wave has here and spills (measured: 0.82 -> 0.73 ms on the fc1 GEMM)
+            if (EPI == CHB_EPI_GELU) __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (p.colsum) {   // this wave's 128 rows x 64 columns: fold the 4 row-groups (lanes cr) and add once per column
@@ -343,6 +347,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
 struct TileWalk {
     int start, cnt, slot, stride;   // this workgroup's tiles: start + slot + j*stride, j = 0.. while < cnt
     int tiles_n, ntk;
+    // panel walk (bn > 0): the XCD owns m-tiles [mlo, mlo + mcnt) and sweeps them one bn-wide column of n-tiles at a time,
+    // n fastest; the XCD's 32 concurrent tiles then form a (32/bn) x bn block, the smallest A + B footprint per round
+    int mlo, mcnt, bn;
 };
 
 struct Cursor {   // (output tile, k-tile) position of a staging stream
@@ -355,6 +362,18 @@ __device__ __forceinline__ void cursor_set(Cursor& c, const TileWalk& w, int j) 
     c.kt = 0;
     const int li = w.slot + j * w.stride;
     c.valid = li < w.cnt;
+    if (w.bn > 0) {
+        const int l = c.valid ? li : 0;
+        const int colsz = w.mcnt * w.bn;
+        const int ncols = (w.tiles_n + w.bn - 1) / w.bn;
+        const int sc = min(l / colsz, ncols - 1);
+        const int rem = l - sc * colsz;
+        const int width = min(w.bn, w.tiles_n - sc * w.bn);
+        const int tm = rem / width;
+        c.m0 = (w.mlo + tm) * 256;
+        c.n0 = (sc * w.bn + (rem - tm * width)) * 256;
+        return;
+    }
     const int v = w.start + (c.valid ? li : 0);
     const int tm = v / w.tiles_n;
     c.m0 = tm * 256;
@@ -399,6 +418,20 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         w.stride = gridDim.x >> 3;
         w.tiles_n = p.tiles_n;
         w.ntk = p.K / BK;
+        w.bn = 0; w.mlo = 0; w.mcnt = 0;
+        const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+        // (32 / bn + bn) tiles of A + B per round is smallest near bn = sqrt(32); the panel walk is taken when the m-tiles split
+        // over the XCDs with <= 1/16 imbalance and the footprint shrinks by a quarter or more (N = 3072 here: L2-side fetch
+        // 1.7 GB -> 1.1 GB per launch, profiles/); narrower outputs keep the linear walk, which measured a few % faster there
+        const int ncols = max(1, (int)((float)p.tiles_n / 5.66f + 0.5f));
+        const int bn = (p.tiles_n + ncols - 1) / ncols;
+        const bool pays = 4.0f * (32.0f / p.tiles_n + p.tiles_n) >= 5.0f * (32.0f / bn + bn);
+        if (qm >= 16 && (p.walk_panel == 2 || (p.walk_panel == 1 && pays))) {
+            w.mlo = x * qm + min(x, rm);
+            w.mcnt = qm + (x < rm ? 1 : 0);
+            w.cnt = w.mcnt * p.tiles_n;
+            w.bn = bn;
+        }
     }
     if (w.slot >= w.cnt) return;
     const int nmy = (w.cnt - w.slot + w.stride - 1) / w.stride;
@@ -1156,6 +1189,10 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
     p.drop_key = drop_key;
     p.tiles_m = chb_div_up(M, BM); p.tiles_n = chb_div_up(N, BN);
     p.colsum = out_colsum;
+    {
+        const char* e = getenv("CHB_GEMM_WALK");   // 0 = linear tile ids per XCD, 1 (default) = panel walk where it pays, 2 = always panel
+        p.walk_panel = e ? atoi(e) : 1;
+    }
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         int rc;

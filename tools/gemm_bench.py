@@ -31,8 +31,10 @@ if which in ("all", "nt"):
         out = torch.empty(m, n, dtype=torch.float32 if epi == K.EPI_RESID else torch.bfloat16, device="cuda")
         aux = torch.randn(m, n, device="cuda").to(torch.bfloat16) if epi in (K.EPI_GELU, K.EPI_DGELU) else None
         resid = torch.randn(m, n, device="cuda") if epi == K.EPI_RESID else None
-        ms = timeit(lambda: K.gemm_nt(a, b, out, bias=bias, epilogue=epi, aux=aux, resid=resid, drop_rate=0.1 if epi == K.EPI_RESID else 0.0, drop_key=5))
-        print("%-10s M=%d N=%d K=%d epi=%d  %.3f ms  %.1f TF/s" % (name, m, n, k, epi, ms, 2.0 * m * n * k / ms / 1e9), flush=True)
+        for walk in os.environ.get("GEMM_BENCH_WALKS", "1").split(","):
+            os.environ["CHB_GEMM_WALK"] = walk
+            ms = timeit(lambda: K.gemm_nt(a, b, out, bias=bias, epilogue=epi, aux=aux, resid=resid, drop_rate=0.1 if epi == K.EPI_RESID else 0.0, drop_key=5))
+            print("%-10s M=%d N=%d K=%d epi=%d walk=%s  %.3f ms  %.1f TF/s" % (name, m, n, k, epi, walk, ms, 2.0 * m * n * k / ms / 1e9), flush=True)
 if which in ("all", "tn"):
     for name, m, kd, nd in SHAPES_TN:
         x = torch.randn(m, kd, device="cuda").to(torch.bfloat16)
