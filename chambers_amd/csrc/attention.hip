@@ -177,13 +177,14 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------ backward
 // LDS: K, V, Q, dO images [NP][64] (row-read swizzle; transposed reads take a 2-way conflict),
 // dS double buffer [2][32][NP + 8], lse*log2e and delta per query.
-template <int NTP, bool DROP>
-__global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+template <int NTP, bool DROP, int NW>   // NW waves per workgroup: 8, or 16 (4 per SIMD, <= 128 registers) for 129..224 tokens
+__global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, float scale,
                                                        float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key,
                                                        float* __restrict__ dbias) {
     constexpr int NP = 32 * NTP, NT = 2 * NTP;
-    constexpr int MT = (NT + 7) / 8;   // key tiles owned by one wave (wave w of 8: tiles w, w+8, ...)
+    constexpr int MT = (NT + NW - 1) / NW;   // key tiles owned by one wave (wave w of NW: tiles w, w + NW, ...)
+    constexpr int NTHR = NW * 64;
     constexpr int DSLD = NP + 8;       // dS row stride (elements)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
@@ -203,11 +204,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
     const bf16_t* obase = o + (int64_t)b * N * Dm + h * HD;
     const bf16_t* gbase = d_o + (int64_t)b * N * Dm + h * HD;
 
-    stage_rows<false, 512>(base, D3, N, NP, Qs, tid);
-    stage_rows<false, 512>(base + Dm, D3, N, NP, Ks, tid);
-    stage_rows<false, 512>(base + 2 * Dm, D3, N, NP, Vs, tid);
+    stage_rows<false, NTHR>(base, D3, N, NP, Qs, tid);
+    stage_rows<false, NTHR>(base + Dm, D3, N, NP, Ks, tid);
+    stage_rows<false, NTHR>(base + 2 * Dm, D3, N, NP, Vs, tid);
     // dO image + delta[q] = sum_d dO*O (8 threads per row, one 16-byte chunk each)
-    for (int id = tid; id < ((NP * 8 + 511) & ~511); id += 512) {   // full waves only: the reduction below shuffles
+    for (int id = tid; id < ((NP * 8 + NTHR - 1) & ~(NTHR - 1)); id += NTHR) {   // full waves only: the reduction below shuffles
         const int r = id >> 3, c = id & 7;
         uint4 gv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
         if (r < N && r < NP) {
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
         d += __shfl_xor(d, 4, 64);
         if (c == 0 && r < NP) delta[r] = d;
     }
-    for (int r = tid; r < NP; r += 512) lse2[r] = r < N ? lse[(int64_t)bh * N + r] * 1.44269504088896340736f : INFINITY;
+    for (int r = tid; r < NP; r += NTHR) lse2[r] = r < N ? lse[(int64_t)bh * N + r] * 1.44269504088896340736f : INFINITY;
     __syncthreads();
 
     float4_t dk[4][MT], dv[4][MT];
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
     for (int c = 0; c < MT; ++c)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int t = min(wave + 8 * c, NT - 1);
+            const int t = min(wave + NW * c, NT - 1);
             kfr[c][ks] = lds_row_frag(Ks, 16 * t + i, 4 * ks + g);
             vfr[c][ks] = lds_row_frag(Vs, 16 * t + i, 4 * ks + g);
         }
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
                 erow[qs][r] = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + 16 * qs + 4 * g + r, N - 1)) * (uint32_t)N;
 #pragma unroll
         for (int c = 0; c < MT; ++c) {
-            const int t = wave + 8 * c;
+            const int t = wave + NW * c;
             if (t < NT) {  // wave-uniform
                 const int key = 16 * t + i;
                 const bool tile_full = 16 * t + 16 <= N;   // wave-uniform
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
         }
         }   // phase A
         // ---- phase B (block it - 1): dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; wave w owns query sub-tile w>>2, d-tile w&3
-        if (it > 0) {
+        if (it > 0 && wave < 8) {   // wave-uniform
             const int q0 = 32 * (it - 1);
             const bf16_t* dSb = dSs + ((it - 1) & 1) * 32 * DSLD;
             const int qs = wave >> 2, dtw = wave & 3;
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
     // dK^T / dV^T accumulators: lane (g,i) reg r = [d = 16dt + 4g + r][key = 16t + i]
 #pragma unroll
     for (int c = 0; c < MT; ++c) {
-        const int t = wave + 8 * c;
+        const int t = wave + NW * c;
         const int key = 16 * t + i;
         if (t < NT && key < N) {
             bf16_t* kp = dqkv + ((int64_t)b * N + key) * D3 + Dm + h * HD;
@@ -378,6 +379,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
         const int dtw = wave & 3;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (wave >= 8) break;   // dQ tiles belong to waves 0..7
             float v = dqsum[r];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
             if (i == 0) atomicAdd(dbias + h * HD + 16 * dtw + 4 * g + r, v);
@@ -389,8 +391,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(const bf16_t* __restri
                 float vk = 0.f, vv = 0.f;
 #pragma unroll
                 for (int c = 0; c < MT; ++c) {
-                    const int key = 16 * (wave + 8 * c) + i;
-                    if (wave + 8 * c < NT && key < N) {
+                    const int key = 16 * (wave + NW * c) + i;
+                    if (wave + NW * c < NT && key < N) {
                         vk += dk[dt][c][r];
                         vv += dv[dt][c][r];
                     }
@@ -942,21 +944,22 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
         CHB_LAUNCH_CHECK();
         return CHB_OK;
     }
-#define CHB_BWD(NTP)                                                                                                             \
+#define CHB_BWD(NTP, NW)                                                                                                             \
     do {                                                                                                                         \
         const size_t lds = bwd_lds_bytes<NTP>();                                                                                 \
-        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
-            hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
+            hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
             return CHB_ELAUNCH;                                                                                                  \
-        if (thr) hipLaunchKernelGGL((attn_bwd_kernel<NTP, true>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
+        if (thr) hipLaunchKernelGGL((attn_bwd_kernel<NTP, true, NW>), grid, dim3(NW * 64), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
                            lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);                           \
-        else hipLaunchKernelGGL((attn_bwd_kernel<NTP, false>), grid, block, lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
+        else hipLaunchKernelGGL((attn_bwd_kernel<NTP, false, NW>), grid, dim3(NW * 64), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
                            lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);                           \
     } while (0)
-    if (N <= 32) CHB_BWD(1);
-    else if (N <= 64) CHB_BWD(2);
-    else if (N <= 128) CHB_BWD(4);
-    else CHB_BWD(7);
+    if (N <= 32) CHB_BWD(1, 8);
+    else if (N <= 64) CHB_BWD(2, 8);
+    else if (N <= 128) CHB_BWD(4, 8);
+    else if (algo_env && atoi(algo_env) == 1) CHB_BWD(7, 8);   // 8-wave variant kept for A/B timing
+    else CHB_BWD(7, 16);
 #undef CHB_BWD
     CHB_LAUNCH_CHECK();
     return CHB_OK;

@@ -31,10 +31,10 @@ for rate in (0.0, 0.1):
         os.environ["CHB_ATTN_FWD_ALGO"] = algo
         f = t(lambda: K.attention_fwd(qkv, o, lse, B, N, H, 64, rate, 7))
         line += "   fwd[%s] %.3f ms (%.0f TF/s)" % ("resident" if algo == "1" else "stream", f, fl / f / 1e9)
-    for algo in ("1", "2"):
+    for algo, label in (("0", "default"), ("1", "resident 8 waves"), ("2", "two-pass")):
         if algo == "1" and N > 224:
             continue
         os.environ["CHB_ATTN_BWD_ALGO"] = algo
         b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7))
-        line += "   bwd[%s-pass] %.3f ms (%.0f TF/s)" % (algo, b, 2.5 * fl / b / 1e9)
+        line += "   bwd[%s] %.3f ms (%.0f TF/s)" % (label, b, 2.5 * fl / b / 1e9)
     print(line, flush=True)
