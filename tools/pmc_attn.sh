@@ -11,7 +11,7 @@ for f in glob.glob("gpurun_out/pmca_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "attn" not in k: continue
-        k = k.split("(")[0].replace("void (anonymous namespace)::", "")
+        k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items()):
     print(k)

@@ -4,6 +4,7 @@
 # per-launch averages with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE (KB) x 2 for
 # wide coalesced reads, WRITE_SIZE (KB) as is.  Output: gpurun_out/bench_pmc_traffic.json (copy to profiles/).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/pmcb_FETCH_SIZE gpurun_out/pmcb_WRITE_SIZE
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcb_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcb_$c.log 2>&1 || exit 1
 done

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Per-shape HBM-side traffic of the GEMM micro-benchmark: FETCH_SIZE / WRITE_SIZE passes, dispatches mapped to shapes by order.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/pmcg_FETCH_SIZE gpurun_out/pmcg_WRITE_SIZE
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcg_$c -- python tools/gemm_bench.py 2 ${1:-all} > gpurun_out/pmcg_$c.log 2>&1 || exit 1
 done
