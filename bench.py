@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-augment", action="store_true")
+    ap.add_argument("--augment", default="randaugment", choices=("randaugment", "autoaugment"),
+                    help="on-GPU augmentation stage: RandAugment(2, 9) (configs 3/4) or AutoAugment policy v0 (config 5)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N ranks on one GPU")
     args = ap.parse_args()
 
@@ -195,11 +197,17 @@ def main():
     labels = torch.as_tensor(g.integers(0, 1000, size=(args.batch,)), device="cuda")
     gd = np.random.Generator(np.random.PCG64(42 + rank))            # augmentation decisions, host side
     randaug = aug.RandAugment(2, 9)
+    autoaug = aug.AutoAugment()
 
     def step():
         x = images
         if not args.no_augment:
-            x = randaug(images, training=True, decisions=draw_randaugment_decisions(gd, 2, args.batch, args.image_size, args.image_size))
+            if args.augment == "autoaugment":
+                pol = int(gd.integers(0, 25))
+                x = autoaug(images, training=True, decision={"policy": pol, "apply": (bool(gd.uniform() < 0.5), bool(gd.uniform() < 0.5)),
+                                                             "negate": (bool(gd.uniform() < 0.5), bool(gd.uniform() < 0.5))})
+            else:
+                x = randaug(images, training=True, decisions=draw_randaugment_decisions(gd, 2, args.batch, args.image_size, args.image_size))
         return eng.train_step(x, labels, learning_rate=1e-3, weight_decay=0.05)
 
     for _ in range(args.warmup):
@@ -236,8 +244,10 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s train step, batch %d/GPU, %dx%d, on-GPU RandAugment(n=2,m=9)%s, dropout 0.1, AdamW, dp%d"
-                       % (args.model, args.batch, args.image_size, args.image_size, " OFF" if args.no_augment else "", world),
+            "config": {"workload": "%s train step, batch %d/GPU, %dx%d, on-GPU %s%s, dropout 0.1, AdamW, dp%d"
+                       % (args.model, args.batch, args.image_size, args.image_size,
+                          "AutoAugment(policy v0)" if args.augment == "autoaugment" else "RandAugment(n=2,m=9)",
+                          " OFF" if args.no_augment else "", world),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ks[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ks[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
