@@ -148,6 +148,22 @@ def pmc_traffic(kernel):
     return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": "profiles/" + os.path.basename(files[-1])}
 
 
+def ensure_library(local_rank):
+    """The HIP library normally travels prebuilt with the tree (__graft_entry__.build()); if its stamp is stale or it is
+    missing, local rank 0 compiles it (hipcc is on the GPU box) and the other ranks wait for the stamp."""
+    from chambers_amd import _build
+    if _build.is_current():
+        return
+    if local_rank == 0:
+        _build.build(verbose=False)
+        return
+    deadline = time.time() + 900
+    while not _build.is_current():
+        if time.time() > deadline:
+            raise RuntimeError("libchambers_hip.so was not built by local rank 0 within 15 minutes")
+        time.sleep(2.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +188,7 @@ def main():
         args.gpus = world
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    ensure_library(int(os.environ.get("LOCAL_RANK", "0")))
     dist = None
     if world > 1:
         import torch.distributed as dist
