@@ -122,6 +122,12 @@ class Model(Layer):
         with np.load(path) as z:
             self.assign_keras_weights({k: z[k] for k in z.files})
 
+    def load_timm_state_dict(self, state_dict):
+        """Import a timm ViT `state_dict()` (or any name -> array mapping with timm's keys) through the conversion rules of
+        test_units/manual_test_vit_weights.py:27-155 (chambers_amd.utils.weights)."""
+        from ...utils.weights import timm_state_dict_to_keras
+        self.assign_keras_weights(timm_state_dict_to_keras(state_dict, self.cfg.n_heads, include_top=self.cfg.include_top))
+
     def save_weights(self, path):
         np.savez(path, **self.keras_weights())
 

@@ -59,3 +59,38 @@ def test_adamw_restatement_known_answer():
     np.testing.assert_allclose(p["w"].numpy(), [0.99 - 1e-3, -1.98 - 1e-3], rtol=0, atol=2e-6)
     np.testing.assert_allclose(m["w"].numpy(), [0.05, 0.025], rtol=1e-6)
     np.testing.assert_allclose(v["w"].numpy(), [0.00025, 0.0000625], rtol=2e-5)   # (1 - 0.999f) in float32, as keras computes it
+
+
+def test_timm_state_dict_import_matches_timm_forward():
+    """chambers_amd.utils.weights.timm_state_dict_to_keras: a random timm-layout ViT evaluated the timm way (F.linear on the
+    original tensors, fused qkv, conv patch embedding) equals the oracle's chambers graph on the converted weights — the
+    equivalence the reference asserts in test_units/manual_test_vit_weights.py:252-341, here for the whole model."""
+    from chambers_amd.utils.weights import timm_state_dict_to_keras
+    g = torch.Generator().manual_seed(3)
+    d, heads, ff, p, L, classes = 64, 2, 96, 8, 2, 5
+    hgt, wid = 24, 16
+    n = (hgt // p) * (wid // p) + 1
+    r = lambda *s, sc=0.1: torch.randn(*s, generator=g) * sc   # noqa: E731
+    sd = {"patch_embed.proj.weight": r(d, 3, p, p), "patch_embed.proj.bias": r(d), "cls_token": r(1, 1, d), "pos_embed": r(1, n, d),
+          "norm.weight": 1 + r(d), "norm.bias": r(d), "head.weight": r(classes, d), "head.bias": r(classes)}
+    for i in range(L):
+        t = "blocks.%d." % i
+        sd.update({t + "norm1.weight": 1 + r(d), t + "norm1.bias": r(d), t + "attn.qkv.weight": r(3 * d, d), t + "attn.qkv.bias": r(3 * d),
+                   t + "attn.proj.weight": r(d, d), t + "attn.proj.bias": r(d), t + "norm2.weight": 1 + r(d), t + "norm2.bias": r(d),
+                   t + "mlp.fc1.weight": r(ff, d), t + "mlp.fc1.bias": r(ff), t + "mlp.fc2.weight": r(d, ff), t + "mlp.fc2.bias": r(d)})
+    x = torch.randn(2, hgt, wid, 3, generator=g)                                  # NHWC, already normalised
+    # timm forward: Conv2d(stride = kernel = p) on NCHW, flatten, cls token, pos embed, blocks, norm, cls pooling, head
+    t = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=p)
+    t = t.flatten(2).transpose(1, 2)
+    t = torch.cat([sd["cls_token"].expand(2, -1, -1), t], dim=1) + sd["pos_embed"]
+    for i in range(L):
+        pre = "blocks.%d." % i
+        t = vit_ref.timm_block(t, {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, heads)
+    t = torch.nn.functional.layer_norm(t, (d,), sd["norm.weight"], sd["norm.bias"], 1e-6)
+    ref = torch.nn.functional.linear(t[:, 0], sd["head.weight"], sd["head.bias"])
+    kw = timm_state_dict_to_keras(sd, heads)
+    cfg = {"patch_size": p, "n_encoder_layers": L, "n_heads": heads, "dropout_rate": 0.0}
+    out = vit_ref.vit_forward({k: torch.tensor(v) for k, v in kw.items()}, x, cfg)
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-5), float((out - ref).abs().max())
+    assert kw["encoder/layer_1/multi_head_attention/w_key"].shape == (d, heads, d // heads)
+    assert kw["patch_embeddings/embedding/kernel"].shape == (p, p, 3, d)
