@@ -43,7 +43,9 @@ PROTOTYPES = {
     "chb_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P],
     "chb_attention_bwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P],
     "chb_cls_row": [P, P, P, c_int, c_int, c_int, c_float, c_uint32, P],
+    "chb_token_row": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P],
     "chb_embed_bwd": [P, P, P, P, c_int, c_int, c_int, c_float, c_uint32, P],
+    "chb_embed_bwd_tokens": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P],
     "chb_dropout_bwd_bf16": [P, c_int64, P, c_int, c_int, c_float, c_uint32, P],
     "chb_colsum_bf16": [P, c_int64, P, c_int, c_int, P],
     "chb_softmax_ce": [P, c_int64, P, P, P, c_int64, c_int, c_int, c_float, P],

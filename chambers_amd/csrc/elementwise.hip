@@ -21,22 +21,22 @@ __global__ void dropout_mask_kernel(uint8_t* out, int64_t n, uint32_t thr, uint3
         out[e] = chb_keep((uint64_t)e, key, thr) ? 1 : 0;
 }
 
-__global__ void cls_row_kernel(float* x, const float* cls, const float* pos, int B, int N, int D, float scale, uint32_t thr,
+__global__ void cls_row_kernel(float* x, const float* cls, const float* pos, int B, int N, int D, int row, float scale, uint32_t thr,
                                uint32_t key) {
     const int64_t total = (int64_t)B * D;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(t / D), d = (int)(t - (int64_t)b * D);
-        const int64_t e = (int64_t)b * N * D + d;
-        float v = cls[d] + pos[d];
+        const int64_t e = ((int64_t)b * N + row) * D + d;
+        float v = cls[d] + pos[(int64_t)row * D + d];
         if (thr) v = chb_keep((uint64_t)e, key, thr) ? v * scale : 0.f;
         x[e] = v;
     }
 }
 
-// thread = (token t, 4 columns); loops over the batch: dpos[t] = sum_b dz[b,t], dcls = dpos[0],
-// dpatch[b, t-1] = bf16(dz[b,t]) for t >= 1, with dz = dx * keep * scale.
+// thread = (token t, 4 columns); loops over the batch: dpos[t] = sum_b dz[b,t], dtok[t] = dpos[t] for the ns special tokens,
+// dpatch[b, t-ns] = bf16(dz[b,t]) for t >= ns, with dz = dx * keep * scale.
 __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dpatch, float* __restrict__ dpos,
-                                                        float* __restrict__ dcls, int B, int N, int D, float scale, uint32_t thr,
+                                                        float* __restrict__ dcls, int B, int N, int D, int ns, float scale, uint32_t thr,
                                                         uint32_t key) {
     const int dq = D >> 2;
     const int64_t total = (int64_t)N * dq;
@@ -54,15 +54,15 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict_
                 v.z = k2 ? v.z * scale : 0.f; v.w = k3 ? v.w * scale : 0.f;
             }
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            if (t >= 1) {
+            if (t >= ns) {
                 uint2 o;
                 o.x = pack_bf16x2(v.x, v.y);
                 o.y = pack_bf16x2(v.z, v.w);
-                *reinterpret_cast<uint2*>(dpatch + ((int64_t)b * (N - 1) + (t - 1)) * D + d) = o;
+                *reinterpret_cast<uint2*>(dpatch + ((int64_t)b * (N - ns) + (t - ns)) * D + d) = o;
             }
         }
         *reinterpret_cast<float4*>(dpos + (int64_t)t * D + d) = acc;
-        if (t == 0) *reinterpret_cast<float4*>(dcls + d) = acc;
+        if (t < ns) *reinterpret_cast<float4*>(dcls + (int64_t)t * D + d) = acc;   // special tokens: class (row 0), distillation (row 1)
     }
 }
 
@@ -284,22 +284,35 @@ int chb_dropout_mask(uint8_t* out, int64_t n, float rate, uint32_t key, void* st
     return CHB_OK;
 }
 
-int chb_cls_row(float* x, const float* cls, const float* pos, int B, int N, int D, float drop_rate, uint32_t drop_key, void* stream) {
-    if (!x || !cls || !pos || B < 0 || N <= 0 || D <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
+int chb_token_row(float* x, const float* tok, const float* pos, int B, int N, int D, int row, float drop_rate, uint32_t drop_key,
+                  void* stream) {
+    if (!x || !tok || !pos || B < 0 || N <= 0 || D <= 0 || row < 0 || row >= N || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
     if (B == 0) return CHB_OK;
-    hipLaunchKernelGGL(cls_row_kernel, dim3(grid_for((int64_t)B * D)), dim3(256), 0, (hipStream_t)stream, x, cls, pos, B, N, D,
+    hipLaunchKernelGGL(cls_row_kernel, dim3(grid_for((int64_t)B * D)), dim3(256), 0, (hipStream_t)stream, x, tok, pos, B, N, D, row,
                        1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_cls_row(float* x, const float* cls, const float* pos, int B, int N, int D, float drop_rate, uint32_t drop_key, void* stream) {
+    return chb_token_row(x, cls, pos, B, N, D, 0, drop_rate, drop_key, stream);
+}
+
+int chb_embed_bwd_tokens(const float* dx, void* dpatch, float* dpos, float* dtok, int B, int N, int D, int n_special, float drop_rate,
+                         uint32_t drop_key, void* stream) {
+    if (!dx || !dpatch || !dpos || !dtok || B < 0 || n_special < 1 || N <= n_special || D <= 0 || (D & 3) || drop_rate < 0.f ||
+        drop_rate >= 1.f)
+        return CHB_EINVAL;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((int64_t)N * (D / 4))), dim3(256), 0, (hipStream_t)stream, dx, (bf16_t*)dpatch,
+                       dpos, dtok, B, N, D, n_special, 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u,
+                       drop_key);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }
 
 int chb_embed_bwd(const float* dx, void* dpatch, float* dpos, float* dcls, int B, int N, int D, float drop_rate, uint32_t drop_key,
                   void* stream) {
-    if (!dx || !dpatch || !dpos || !dcls || B < 0 || N <= 1 || D <= 0 || (D & 3) || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((int64_t)N * (D / 4))), dim3(256), 0, (hipStream_t)stream, dx, (bf16_t*)dpatch,
-                       dpos, dcls, B, N, D, 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key);
-    CHB_LAUNCH_CHECK();
-    return CHB_OK;
+    return chb_embed_bwd_tokens(dx, dpatch, dpos, dcls, B, N, D, 1, drop_rate, drop_key, stream);
 }
 
 int chb_dropout_bwd_bf16(const float* dy, int64_t ld, void* dz, int M, int N, float drop_rate, uint32_t drop_key, void* stream) {

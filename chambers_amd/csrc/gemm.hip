@@ -30,7 +30,8 @@ struct GemmParams {
     const float* bias;
     bf16_t* aux; int64_t ld_aux;
     const float* resid; int64_t ld_resid;
-    int period;
+    int period;      // PATCH: patches per image
+    int n_special;   // PATCH: tokens in front of the patches (1 = class token, 2 = class + distillation token)
     float drop_scale; uint32_t drop_thr; uint32_t drop_key;
     int tiles_m, tiles_n;
     float* colsum;   // optional fp32 [N]: += column sums of the output (bias gradient of the consumer layer)
@@ -81,8 +82,8 @@ __device__ __forceinline__ void epilogue_row(const GemmParams& p, int row, int c
     const float* posrow = nullptr;
     if (EPI == CHB_EPI_PATCH) {
         const int b = row / p.period, pp = row - b * p.period;
-        orow = (int64_t)b * (p.period + 1) + 1 + pp;
-        posrow = p.resid + (int64_t)(1 + pp) * p.ld_resid;
+        orow = (int64_t)b * (p.period + p.n_special) + p.n_special + pp;
+        posrow = p.resid + (int64_t)(p.n_special + pp) * p.ld_resid;
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -268,8 +269,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
             ok[k] = colok && (!GUARD || row < p.M);
             if (EPI == CHB_EPI_PATCH) {
                 const int bi = row / p.period, pp = row - bi * p.period;
-                orow[k] = (int64_t)bi * (p.period + 1) + 1 + pp;
-                if (ok[k]) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(1 + pp) * p.ld_resid + col);
+                orow[k] = (int64_t)bi * (p.period + p.n_special) + p.n_special + pp;
+                if (ok[k]) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.n_special + pp) * p.ld_resid + col);
             }
             if (EPI == CHB_EPI_RESID && ok[k]) r4[k] = *reinterpret_cast<const float4*>(rbase + rr * rstep);
             if (EPI == CHB_EPI_DGELU && ok[k]) a2[k] = *reinterpret_cast<const uint2*>(abase + rr * astep);
@@ -730,8 +731,8 @@ __device__ __forceinline__ void epilogue_staged32(const GemmParams& p, float* st
                 ok[k] = colok && (!GUARD || row < p.M);
                 if (EPI == CHB_EPI_PATCH) {
                     const int bi = row / p.period, pp = row - bi * p.period;
-                    orow[k] = (int64_t)bi * (p.period + 1) + 1 + pp;
-                    if (ok[k]) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(1 + pp) * p.ld_resid + col);
+                    orow[k] = (int64_t)bi * (p.period + p.n_special) + p.n_special + pp;
+                    if (ok[k]) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.n_special + pp) * p.ld_resid + col);
                 }
                 if (EPI == CHB_EPI_RESID && ok[k]) r4[k] = *reinterpret_cast<const float4*>(rbase + rr * rstep);
                 if (EPI == CHB_EPI_DGELU && ok[k]) a2[k] = *reinterpret_cast<const uint2*>(abase + rr * astep);
@@ -1183,7 +1184,9 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
     GemmParams p;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.bias = bias; p.aux = (bf16_t*)aux; p.ld_aux = ld_aux;
-    p.resid = resid; p.ld_resid = ld_resid; p.period = period;
+    p.resid = resid; p.ld_resid = ld_resid;
+    p.period = period & 0xffffff;             // bits 0..23: patches per image
+    p.n_special = 1 + ((period >> 24) & 15);  // bits 24..27: special tokens beyond the class token
     p.drop_thr = drop_rate > 0.0f ? chb_drop_threshold(drop_rate) : 0u;
     p.drop_scale = 1.0f / (1.0f - drop_rate);
     p.drop_key = drop_key;

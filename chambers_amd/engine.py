@@ -35,7 +35,8 @@ def _round_up(x, m):
 
 class ViTConfig:
     def __init__(self, patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate=0.1, image_size=(224, 224),
-                 classes=1000, include_top=True, feature_dim=None, pooling="cls", norm_epsilon=1e-6, norm_mode="tf"):
+                 classes=1000, include_top=True, feature_dim=None, pooling="cls", norm_epsilon=1e-6, norm_mode="tf",
+                 distilled=False, return_dist_token=True):
         self.patch_size, self.patch_dim, self.n_encoder_layers = int(patch_size), int(patch_dim), int(n_encoder_layers)
         self.n_heads, self.ff_dim, self.dropout_rate = int(n_heads), int(ff_dim), float(dropout_rate)
         self.image_size = (int(image_size[0]), int(image_size[1]))
@@ -49,12 +50,18 @@ class ViTConfig:
         self.feature_pad = _round_up(int(feature_dim), 64) if feature_dim else 0
         self.grid = (self.image_size[0] // self.patch_size, self.image_size[1] // self.patch_size)
         self.n_patches = self.grid[0] * self.grid[1]
-        self.n_tokens = self.n_patches + 1
+        # DistilledVisionTransformer (vision_transformer.py:295-400): a distillation token after the class token, a second head
+        self.distilled, self.return_dist_token = bool(distilled), bool(return_dist_token)
+        if self.distilled and feature_dim:
+            raise ValueError("the distilled variant has no feature head (vision_transformer.py:295-311)")
+        self.n_special = 2 if self.distilled else 1
+        self.n_tokens = self.n_patches + self.n_special
         self.patch_k = self.patch_size * self.patch_size * 3
 
     def as_oracle_cfg(self):
         return {"patch_size": self.patch_size, "n_encoder_layers": self.n_encoder_layers, "n_heads": self.n_heads,
-                "dropout_rate": self.dropout_rate, "norm_epsilon": self.norm_epsilon, "pooling": None if self.pooling == "none" else self.pooling}
+                "dropout_rate": self.dropout_rate, "norm_epsilon": self.norm_epsilon, "pooling": None if self.pooling == "none" else self.pooling,
+                "return_dist_token": self.return_dist_token}
 
 
 class ParamSpec:
@@ -86,6 +93,9 @@ def build_param_table(cfg, decay_fn=None):
         in_dim = cfg.feature_pad or d
         add("predictions/kernel", (in_dim, cpad), True)
         add("predictions/bias", (cpad,), False)
+        if cfg.distilled:
+            add("predictions_dist/kernel", (d, cpad), True)
+            add("predictions_dist/bias", (cpad,), False)
     if cfg.feature_dim:
         add("feature/kernel", (d, cfg.feature_pad), True)
         add("feature/bias", (cfg.feature_pad,), False)
@@ -110,7 +120,7 @@ def build_param_table(cfg, decay_fn=None):
         buckets.append((start, off))
     start = off
     add("pos_embedding/embeddings", (n, d), False)
-    add("add_cls_token/embeddings", (d,), False)
+    add("add_cls_token/embeddings", (cfg.n_special, d), False)     # row 0 class token, row 1 distillation token (distilled variant)
     add("patch_embeddings/embedding/kernel", (kp, d), True)
     add("patch_embeddings/embedding/bias", (d,), False)
     buckets.append((start, off))
@@ -128,7 +138,8 @@ def keras_variable_names(cfg):
 
     names = {"patch_embeddings/embedding/kernel": ["patch_embeddings/embedding/kernel:0"],
              "patch_embeddings/embedding/bias": ["patch_embeddings/embedding/bias:0"],
-             "add_cls_token/embeddings": ["add_cls_token/embeddings:0"], "pos_embedding/embeddings": ["pos_embedding/embeddings:0"]}
+             "add_cls_token/embeddings": ["add_cls_token/embeddings:0"] + (["add_dist_token/embeddings:0"] if cfg.distilled else []),
+             "pos_embedding/embeddings": ["pos_embedding/embeddings:0"]}
     L = cfg.n_encoder_layers
     for i in range(L):
         p = "encoder/layer_%d/" % i
@@ -149,6 +160,8 @@ def keras_variable_names(cfg):
         names["feature/kernel"], names["feature/bias"] = ["feature/kernel:0"], ["feature/bias:0"]
     if cfg.include_top:
         names["predictions/kernel"], names["predictions/bias"] = ["predictions/kernel:0"], ["predictions/bias:0"]
+        if cfg.distilled:
+            names["predictions_dist/kernel"], names["predictions_dist/bias"] = ["predictions_dist/kernel:0"], ["predictions_dist/bias:0"]
     return names
 
 
@@ -175,7 +188,10 @@ def keras_to_internal(kw, cfg):
     out = {}
     out["patch_embeddings/embedding/kernel"] = np.asarray(kw["patch_embeddings/embedding/kernel"]).reshape(cfg.patch_k, d)
     out["patch_embeddings/embedding/bias"] = np.asarray(kw["patch_embeddings/embedding/bias"])
-    out["add_cls_token/embeddings"] = np.asarray(kw["add_cls_token/embeddings"]).reshape(d)
+    toks = [np.asarray(kw["add_cls_token/embeddings"]).reshape(1, d)]
+    if cfg.distilled:
+        toks.append(np.asarray(kw["add_dist_token/embeddings"]).reshape(1, d))
+    out["add_cls_token/embeddings"] = np.concatenate(toks, axis=0)
     out["pos_embedding/embeddings"] = np.asarray(kw["pos_embedding/embeddings"])
     for i in range(cfg.n_encoder_layers):
         p = "encoder/layer_%d/" % i
@@ -204,6 +220,12 @@ def keras_to_internal(kw, cfg):
         bp = np.zeros((cpad,), dtype=np.float32)
         bp[:cfg.classes] = np.asarray(kw["predictions/bias"])
         out["predictions/kernel"], out["predictions/bias"] = kp, bp
+        if cfg.distilled:
+            kd = np.zeros((d, cpad), dtype=np.float32)
+            kd[:, :cfg.classes] = np.asarray(kw["predictions_dist/kernel"])
+            bd = np.zeros((cpad,), dtype=np.float32)
+            bd[:cfg.classes] = np.asarray(kw["predictions_dist/bias"])
+            out["predictions_dist/kernel"], out["predictions_dist/bias"] = kd, bd
     return out
 
 
@@ -213,7 +235,9 @@ def internal_to_keras(iw, cfg):
     out = {}
     out["patch_embeddings/embedding/kernel"] = iw["patch_embeddings/embedding/kernel"].reshape(p_, p_, 3, d)
     out["patch_embeddings/embedding/bias"] = iw["patch_embeddings/embedding/bias"]
-    out["add_cls_token/embeddings"] = iw["add_cls_token/embeddings"].reshape(1, d)
+    out["add_cls_token/embeddings"] = iw["add_cls_token/embeddings"].reshape(cfg.n_special, d)[0:1]
+    if cfg.distilled:
+        out["add_dist_token/embeddings"] = iw["add_cls_token/embeddings"].reshape(cfg.n_special, d)[1:2]
     out["pos_embedding/embeddings"] = iw["pos_embedding/embeddings"]
     for i in range(cfg.n_encoder_layers):
         p = "encoder/layer_%d/" % i
@@ -234,6 +258,9 @@ def internal_to_keras(iw, cfg):
     if cfg.include_top:
         out["predictions/kernel"] = iw["predictions/kernel"][:cfg.feature_dim or d, :cfg.classes]
         out["predictions/bias"] = iw["predictions/bias"][:cfg.classes]
+        if cfg.distilled:
+            out["predictions_dist/kernel"] = iw["predictions_dist/kernel"][:, :cfg.classes]
+            out["predictions_dist/bias"] = iw["predictions_dist/bias"][:cfg.classes]
     return {k: np.ascontiguousarray(v) for k, v in out.items()}
 
 
@@ -260,9 +287,13 @@ def init_keras_weights(cfg, seed=1234):
     kw["encoder/norm/gamma"], kw["encoder/norm/beta"] = I.ones((d,)), I.zeros((d,))
     if cfg.feature_dim:
         kw["feature/kernel"], kw["feature/bias"] = I.glorot_uniform((d, cfg.feature_dim)), I.zeros((cfg.feature_dim,))
+    if cfg.distilled:
+        kw["add_dist_token/embeddings"] = tn((1, d))
     if cfg.include_top:
         kw["predictions/kernel"] = I.glorot_uniform((cfg.feature_dim or d, cfg.classes))
         kw["predictions/bias"] = I.zeros((cfg.classes,))
+        if cfg.distilled:
+            kw["predictions_dist/kernel"], kw["predictions_dist/bias"] = I.glorot_uniform((d, cfg.classes)), I.zeros((cfg.classes,))
     return kw
 
 
@@ -418,10 +449,19 @@ class ViTEngine:
         if cfg.include_top:
             self.cpad = cfg.classes_pad
             self.logits = z(self.Bp, self.cpad, dtype=f32)
+        if cfg.distilled:
+            self.hfd = z(self.Bp, d)                 # normalised distillation-token embedding
+            self.meand, self.rstdd = z(self.Bp, dtype=f32), z(self.Bp, dtype=f32)
+            if cfg.include_top:
+                self.logits_dist = z(self.Bp, self.cpad, dtype=f32)
         self.loss_vec = z(self.Bp, dtype=f32)
         if self.training:
             if cfg.include_top:
                 self.dlogits = z(self.Bp, self.cpad)
+                if cfg.distilled:
+                    self.dlogits_dist = z(self.Bp, self.cpad)
+            if cfg.distilled:
+                self.dhfd = z(self.Bp, d)
             if F:
                 self.dfeat = z(self.Bp, F, dtype=f32)
                 self.dfz = z(self.Bp, F)
@@ -459,9 +499,11 @@ class ViTEngine:
         x0 = self.xs[0]
         K.gemm_nt(self.patches, self.wbt("patch_embeddings/embedding/kernel"), x0, m=self.Mpatch,
                   bias=self.p("patch_embeddings/embedding/bias"), epilogue=K.EPI_PATCH, resid=self.p("pos_embedding/embeddings"),
-                  period=cfg.n_patches, drop_rate=rate, drop_key=key(rng.SITE_EMBED))
-        K.cls_row(x0, self.p("add_cls_token/embeddings"), self.p("pos_embedding/embeddings"), self.B, cfg.n_tokens, cfg.patch_dim,
-                  drop_rate=rate, drop_key=key(rng.SITE_EMBED))
+                  period=cfg.n_patches | ((cfg.n_special - 1) << 24), drop_rate=rate, drop_key=key(rng.SITE_EMBED))
+        toks = self.p("add_cls_token/embeddings")
+        for row in range(cfg.n_special):     # class token, then the distillation token of the distilled variant
+            K.token_row(x0, toks[row], self.p("pos_embedding/embeddings"), self.B, cfg.n_tokens, cfg.patch_dim, row,
+                        drop_rate=rate, drop_key=key(rng.SITE_EMBED))
         return x0
 
     def block_forward(self, l, x_in, x_out, a, training):
@@ -513,10 +555,30 @@ class ViTEngine:
             K.gemm_nt(self.hf, self.wbt("feature/kernel"), self.feat, m=self.B, bias=self.p("feature/bias"))
             K.tanh_fwd(self.feat, self.feat_b)
             head_in = self.feat_b
+        if cfg.distilled:
+            return self._distilled_heads(x, head_in)
         if not cfg.include_top:
             return self.feat[:self.B, :cfg.feature_dim] if cfg.feature_dim else self.hf[:self.B]
         K.gemm_nt(head_in, self.wbt("predictions/kernel"), self.logits, m=self.B, bias=self.p("predictions/bias"))
         return self.logits[:self.B, :cfg.classes]
+
+    def _distilled_heads(self, x, head_in):
+        """DistilledVisionTransformer outputs (vision_transformer.py:373-397): the pooled class embedding and the distillation
+        token (sequence row 1) each through their own head; a pair, or their average when return_dist_token=False."""
+        cfg = self.cfg
+        d, n = cfg.patch_dim, cfg.n_tokens
+        if cfg.pooling == "cls":
+            K.layernorm_fwd(x.view(-1)[d:], n * d, self.p("encoder/norm/gamma"), self.p("encoder/norm/beta"), self.hfd, self.meand, self.rstdd,
+                            self.B, d, cfg.norm_epsilon)
+        else:
+            self.hfd[:self.B].copy_(self.hn[:self.M].view(self.B, n, d)[:, 1, :])
+        if cfg.include_top:
+            K.gemm_nt(head_in, self.wbt("predictions/kernel"), self.logits, m=self.B, bias=self.p("predictions/bias"))
+            K.gemm_nt(self.hfd, self.wbt("predictions_dist/kernel"), self.logits_dist, m=self.B, bias=self.p("predictions_dist/bias"))
+            a, b = self.logits[:self.B, :cfg.classes], self.logits_dist[:self.B, :cfg.classes]
+        else:
+            a, b = self.hf[:self.B].float(), self.hfd[:self.B].float()
+        return (a, b) if cfg.return_dist_token else (a + b) * 0.5
 
     def loss(self, labels):
         """Sparse softmax cross-entropy from logits, mean over the batch; also fills dlogits when training."""
@@ -536,7 +598,9 @@ class ViTEngine:
         self.G.zero_()
         self.dx.zero_()
         # heads
-        if cfg.include_top:
+        if cfg.distilled:
+            self._distilled_heads_backward(doutput)
+        elif cfg.include_top:
             if doutput is not None:
                 raise ValueError("doutput is for include_top=False models; with a top the gradient comes from loss()")
             K.gemm_tn(self.feat_b if F else self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp)
@@ -559,9 +623,15 @@ class ViTEngine:
         if cfg.pooling == "cls":
             K.layernorm_bwd(self.dhf, self.x_final, n * d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, n * d, False,
                             self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
+            if cfg.distilled:   # the distillation token's rows (sequence row 1) of the same LayerNorm
+                K.layernorm_bwd(self.dhfd, self.x_final.view(-1)[d:], n * d, self.meand, self.rstdd, self.p("encoder/norm/gamma"),
+                                self.dx.view(-1)[d:], n * d, False, self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
         else:
             if cfg.pooling != "none":
                 K.pool_tokens_bwd(self.dhf, self.pool_arg, self.dh, self.B, n, d, cfg.pooling)
+            if cfg.distilled:   # add the distillation head's gradient to row 1 of the normalised sequence
+                dhv = self.dh[:M].view(self.B, n, d)
+                dhv[:, 1, :] += self.dhfd[:self.B]
             K.layernorm_bwd(self.dh, self.x_final, d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, d, False,
                             self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), M, d)
         self.reducer.bucket_ready(0)
@@ -601,10 +671,37 @@ class ViTEngine:
             self.reducer.bucket_ready(L - l)
         # embedding stage
         K.embed_bwd(self.dx, self.dpatch, self.g("pos_embedding/embeddings"), self.g("add_cls_token/embeddings"), self.B, n, d, rate,
-                    key(rng.SITE_EMBED))
+                    key(rng.SITE_EMBED), n_special=cfg.n_special)
         K.gemm_tn(self.patches, self.dpatch, self.g("patch_embeddings/embedding/kernel"), m=self.Mpatch_p)
         K.colsum(self.dpatch, self.g("patch_embeddings/embedding/bias"), m=self.Mpatch)
         self.reducer.bucket_ready(L + 1)
+
+    def _distilled_heads_backward(self, doutput):
+        """d(loss)/d(outputs) of the distilled model: a pair (d_cls, d_dist) of fp32 [B, classes] (or [B, D] without a top), or
+        one tensor for return_dist_token=False (the average passes half of it to each head)."""
+        cfg = self.cfg
+        d = cfg.patch_dim
+        if doutput is None:
+            raise ValueError("the distilled variant has no built-in loss (the reference defines none): pass doutput")
+        if cfg.return_dist_token:
+            da, db = doutput
+        else:
+            da = db = doutput * 0.5
+        width = cfg.classes if cfg.include_top else d
+        if tuple(da.shape) != (self.B, width) or tuple(db.shape) != (self.B, width):
+            raise ValueError("doutput tensors must have shape %s" % ((self.B, width),))
+        if cfg.include_top:
+            self.dlogits[:self.B, :cfg.classes].copy_(da)
+            self.dlogits_dist[:self.B, :cfg.classes].copy_(db)
+            K.gemm_tn(self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp)
+            K.colsum(self.dlogits, self.g("predictions/bias"), m=self.B)
+            K.gemm_nt(self.dlogits, self.wb("predictions/kernel"), self.dhf, m=self.B)
+            K.gemm_tn(self.hfd, self.dlogits_dist, self.g("predictions_dist/kernel"), m=self.Bp)
+            K.colsum(self.dlogits_dist, self.g("predictions_dist/bias"), m=self.B)
+            K.gemm_nt(self.dlogits_dist, self.wb("predictions_dist/kernel"), self.dhfd, m=self.B)
+        else:
+            self.dhf[:self.B].copy_(da)
+            self.dhfd[:self.B].copy_(db)
 
     # ---- optimizer ------------------------------------------------------------------------
     def adamw_step(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, weight_decay=0.0):
@@ -620,9 +717,9 @@ class ViTEngine:
 
     def train_step(self, images_u8, labels, **opt):
         """augmented uint8 batch -> loss vector; runs forward, loss, backward, gradient exchange, AdamW."""
-        if not self.cfg.include_top:
-            raise ValueError("train_step needs the classification top (include_top=True); drive headless models with forward() + "
-                             "backward(doutput) + adamw_step()")
+        if not self.cfg.include_top or self.cfg.distilled:
+            raise ValueError("train_step needs a single classification top (include_top=True, not distilled); drive headless and "
+                             "distilled models with forward() + backward(doutput) + adamw_step()")
         self.forward(images_u8, training=True)
         loss = self.loss(labels)
         self.backward()

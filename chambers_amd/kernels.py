@@ -203,10 +203,18 @@ def cls_row(x, cls, pos, b, n, d, drop_rate=0.0, drop_key=0):
     _lib.call("chb_cls_row", _lib.ptr(x), _lib.ptr(cls), _lib.ptr(pos), int(b), int(n), int(d), float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
 
 
-def embed_bwd(dx, dpatch, dpos, dcls, b, n, d, drop_rate=0.0, drop_key=0):
-    _lib.require_gpu(dx, dpatch, dpos, dcls)
-    _lib.call("chb_embed_bwd", _lib.ptr(dx), _lib.ptr(dpatch), _lib.ptr(dpos), _lib.ptr(dcls), int(b), int(n), int(d), float(drop_rate),
+def token_row(x, tok, pos, b, n, d, row, drop_rate=0.0, drop_key=0):
+    """x[b, row, :] = dropout(tok + pos[row]) — row 0 class token, row 1 distillation token."""
+    _lib.require_gpu(x, tok, pos)
+    _lib.call("chb_token_row", _lib.ptr(x), _lib.ptr(tok), _lib.ptr(pos), int(b), int(n), int(d), int(row), float(drop_rate),
               ctypes.c_uint32(int(drop_key)), _s())
+
+
+def embed_bwd(dx, dpatch, dpos, dtok, b, n, d, drop_rate=0.0, drop_key=0, n_special=1):
+    """dtok: fp32 [n_special, d] (or [d] for the class token alone)."""
+    _lib.require_gpu(dx, dpatch, dpos, dtok)
+    _lib.call("chb_embed_bwd_tokens", _lib.ptr(dx), _lib.ptr(dpatch), _lib.ptr(dpos), _lib.ptr(dtok), int(b), int(n), int(d), int(n_special),
+              float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
 
 
 def dropout_bwd(dy, dz, m, n, drop_rate=0.0, drop_key=0):

@@ -7,7 +7,8 @@ predictions — cf. test_units/manual_test_vit_weights.py:79-155), so timm / Ker
 get_weights()/set_weights().  Execution goes through the whole-model HIP engine (chambers_amd/engine.py).
 
 `pooling` ('cls' | 'avg' | 'max' | 'sum' | None), `feature_dim` (tanh head) and `include_top` follow :172-191,272-283.
-Not built here ("next"): DistilledVisionTransformer / DeiT zoo entries and the pretrained-weight
+`DistilledVisionTransformer` / `DeiTS16` / `DeiTB16` (:295-400, :583-652) add the distillation token and its head.
+Not built here: the pretrained-weight
 download (`weights="imagenet21k+_224"` needs network + .h5); `weights` may be None or a path to an .npz of
 Keras-named arrays."""
 import os
@@ -76,6 +77,8 @@ class Model(Layer):
         emb = self.get_layer("patch_embeddings").get_layer("embedding")
         kw["patch_embeddings/embedding/kernel"], kw["patch_embeddings/embedding/bias"] = emb.kernel.numpy(), emb.bias.numpy()
         kw["add_cls_token/embeddings"] = self.get_layer("add_cls_token").embedding.numpy()
+        if self.cfg.distilled:
+            kw["add_dist_token/embeddings"] = self.get_layer("add_dist_token").embedding.numpy()
         kw["pos_embedding/embeddings"] = self.get_layer("pos_embedding").embedding.numpy()
         enc = self.get_layer("encoder")
         for i, l in enumerate(enc.layers):
@@ -88,7 +91,7 @@ class Model(Layer):
             kw[p + "dense2/kernel"], kw[p + "dense2/bias"] = l.dense2.kernel.numpy(), l.dense2.bias.numpy()
             kw[p + "norm2/gamma"], kw[p + "norm2/beta"] = l.norm2.gamma.numpy(), l.norm2.beta.numpy()
         kw["encoder/norm/gamma"], kw["encoder/norm/beta"] = enc.norm_layer.gamma.numpy(), enc.norm_layer.beta.numpy()
-        for nm in ("feature", "predictions"):
+        for nm in ("feature", "predictions", "predictions_dist"):
             try:
                 l = self.get_layer(nm)
                 kw[nm + "/kernel"], kw[nm + "/bias"] = l.kernel.numpy(), l.bias.numpy()
@@ -100,6 +103,8 @@ class Model(Layer):
         emb = self.get_layer("patch_embeddings").get_layer("embedding")
         emb.kernel.assign(kw["patch_embeddings/embedding/kernel"]); emb.bias.assign(kw["patch_embeddings/embedding/bias"])
         self.get_layer("add_cls_token").embedding.assign(kw["add_cls_token/embeddings"])
+        if self.cfg.distilled:
+            self.get_layer("add_dist_token").embedding.assign(kw["add_dist_token/embeddings"])
         self.get_layer("pos_embedding").embedding.assign(kw["pos_embedding/embeddings"])
         enc = self.get_layer("encoder")
         for i, l in enumerate(enc.layers):
@@ -112,7 +117,7 @@ class Model(Layer):
             l.dense2.kernel.assign(kw[p + "dense2/kernel"]); l.dense2.bias.assign(kw[p + "dense2/bias"])
             l.norm2.gamma.assign(kw[p + "norm2/gamma"]); l.norm2.beta.assign(kw[p + "norm2/beta"])
         enc.norm_layer.gamma.assign(kw["encoder/norm/gamma"]); enc.norm_layer.beta.assign(kw["encoder/norm/beta"])
-        for nm in ("feature", "predictions"):
+        for nm in ("feature", "predictions", "predictions_dist"):
             if nm + "/kernel" in kw:
                 l = self.get_layer(nm)
                 l.kernel.assign(kw[nm + "/kernel"]); l.bias.assign(kw[nm + "/bias"])
@@ -153,7 +158,10 @@ class Model(Layer):
             out = eng.forward(None, training=bool(training), prepatched=True)
         else:
             out = eng.forward(inputs, training=bool(training))
-        if getattr(self, "classifier_activation", None) == "softmax":
+        soft = getattr(self, "classifier_activation", None) == "softmax"
+        if isinstance(out, tuple):                        # distilled variant: [x_cls, x_dist] (vision_transformer.py:392-393)
+            return [torch.softmax(o.float(), dim=-1) if soft else o.clone() for o in out]
+        if soft:
             return torch.softmax(out.float(), dim=-1)     # B x classes; training consumes logits (fused softmax-CE)
         return out.clone()
 
@@ -238,6 +246,65 @@ def VisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, 
     return model
 
 
+def DistilledVisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate=0.1, return_dist_token=True,
+                               input_tensor=None, input_shape=None, include_top=True, weights="imagenet_224", pooling=None, classes=1000,
+                               classifier_activation=None, model_name=None):
+    """vision_transformer.py:295-400: ViT with a distillation token after the class token (`add_dist_token`, then `add_cls_token`,
+    so the sequence is [cls, dist, patches]) and a second head `predictions_dist` on the distillation token.  Outputs
+    `[x_cls, x_dist]`, or their average when return_dist_token=False.  (The reference's default `pooling=None` would feed the
+    whole sequence to the class head; its zoo entries pass "cls", and so must callers here.)"""
+    if weights in _PRETRAINED_TAGS or weights in ("imagenet_224", "imagenet_384"):
+        raise RuntimeError("pretrained weights %r are downloaded from GitHub releases by the reference (vision_transformer.py:149-167); "
+                           "this build has no network path — pass weights=None, an .npz of Keras-named arrays, or use "
+                           "Model.load_timm_state_dict" % (weights,))
+    if classifier_activation not in (None, "linear", "softmax"):
+        raise ValueError("classifier_activation must be None / 'linear' / 'softmax'; got %r" % (classifier_activation,))
+    if pooling is None:
+        raise ValueError("pooling=None hands the whole token sequence to the class head in the reference (vision_transformer.py:373);"
+                         " pass pooling='cls' (what DeiTS16 / DeiTB16 do) or 'avg' / 'max' / 'sum'")
+    shape = _obtain_input_shape(input_tensor, input_shape, default_size=224, min_size=patch_size)
+    cfg = E.ViTConfig(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate, image_size=shape[:2], classes=classes,
+                      include_top=include_top, pooling=pooling, distilled=True, return_dist_token=return_dist_token)
+    tn = initializers.TruncatedNormal(stddev=0.02)
+    patch_embeddings = Sequential([Conv2D(filters=patch_dim, kernel_size=patch_size, strides=patch_size, padding="valid", name="embedding"),
+                                   Reshape([-1, patch_dim])], name="patch_embeddings")
+    add_dist = ConcatEmbedding(n_embeddings=1, embedding_dim=patch_dim, side="left", axis=1, initializer=tn, name="add_dist_token")
+    add_cls = ConcatEmbedding(n_embeddings=1, embedding_dim=patch_dim, side="left", axis=1, initializer=tn, name="add_cls_token")
+    pos = LearnedEmbedding1D(initializer=tn, name="pos_embedding")
+    encoder = Encoder(embed_dim=patch_dim, num_heads=n_heads, ff_dim=ff_dim, num_layers=n_encoder_layers, attention_dropout_rate=dropout_rate,
+                      dense_dropout_rate=dropout_rate, pre_norm=True, norm_output=True, name="encoder")
+    for l in patch_embeddings.layers[:1]:
+        l.build((None,) + shape); l.built = True
+    add_dist.build((None, cfg.n_patches, patch_dim)); add_dist.built = True
+    add_cls.build((None, cfg.n_patches + 1, patch_dim)); add_cls.built = True
+    pos.build((None, cfg.n_tokens, patch_dim)); pos.built = True
+    encoder.build((None, cfg.n_tokens, patch_dim)); encoder.built = True
+    layers = [patch_embeddings, add_dist, add_cls, pos, Dropout(dropout_rate), encoder]
+    if include_top:
+        for nm in ("predictions", "predictions_dist"):
+            head = Dense(units=classes, activation=None if classifier_activation == "linear" else classifier_activation, name=nm)
+            head.build((None, patch_dim)); head.built = True
+            layers.append(head)
+    model = Model(cfg, layers, name=model_name)
+    model.classifier_activation = classifier_activation if include_top else None
+    if weights is not None:
+        if not os.path.exists(str(weights)):
+            raise ValueError("weights file not found: %s" % (weights,))
+        model.load_weights(weights)
+    return model
+
+
+def _deit(model_name, patch_size, patch_dim, n_layers, n_heads, ff_dim):
+    def build(return_dist_token=True, input_tensor=None, input_shape=None, include_top=True, weights="imagenet_224", pooling="cls",
+              classes=1000, classifier_activation=None):
+        return DistilledVisionTransformer(patch_size=patch_size, patch_dim=patch_dim, n_encoder_layers=n_layers, n_heads=n_heads,
+                                          ff_dim=ff_dim, dropout_rate=0.1, return_dist_token=return_dist_token, input_tensor=input_tensor,
+                                          input_shape=input_shape, include_top=include_top, weights=weights, pooling=pooling,
+                                          classes=classes, classifier_activation=classifier_activation, model_name=model_name)
+    build.__name__ = model_name
+    return build
+
+
 def _zoo(model_name, patch_size, patch_dim, n_layers, n_heads, ff_dim, default_weights):
     def build(input_tensor=None, input_shape=None, include_top=True, weights=default_weights, pooling="cls", feature_dim=None, classes=1000,
               classifier_activation=None):
@@ -255,5 +322,8 @@ ViTB16 = _zoo("vitb16", 16, 768, 12, 12, 3072, "imagenet21k+_224")
 ViTB32 = _zoo("vitb32", 32, 768, 12, 12, 3072, "imagenet21k+_384")
 ViTL16 = _zoo("vitl16", 16, 1024, 24, 16, 4096, "imagenet21k+_224")
 ViTL32 = _zoo("vitl32", 32, 1024, 24, 16, 4096, "imagenet21k+_384")
+
+DeiTS16 = _deit("deits16", 16, 384, 12, 6, 1536)      # vision_transformer.py:583-617
+DeiTB16 = _deit("deitb16", 16, 768, 12, 12, 3072)     # :619-652
 
 preprocess_input = ImageNetNormalization(mode="tf", name="vit_preprocess")   # vision_transformer.py:655

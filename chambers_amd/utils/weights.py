@@ -46,6 +46,10 @@ def timm_state_dict_to_keras(state_dict, n_heads, include_top=True):
         out[p + "dense1/kernel"], out[p + "dense1/bias"] = np.ascontiguousarray(sd[t + "mlp.fc1.weight"].T), sd[t + "mlp.fc1.bias"]
         out[p + "dense2/kernel"], out[p + "dense2/bias"] = np.ascontiguousarray(sd[t + "mlp.fc2.weight"].T), sd[t + "mlp.fc2.bias"]
     out["encoder/norm/gamma"], out["encoder/norm/beta"] = sd["norm.weight"], sd["norm.bias"]
+    if "dist_token" in sd:                                     # DeiT distilled checkpoints (manual_test_vit_weights.py:90-99,140-149)
+        out["add_dist_token/embeddings"] = sd["dist_token"].reshape(1, d)
     if include_top:
         out["predictions/kernel"], out["predictions/bias"] = np.ascontiguousarray(sd["head.weight"].T), sd["head.bias"]
+        if "head_dist.weight" in sd:
+            out["predictions_dist/kernel"], out["predictions_dist/bias"] = np.ascontiguousarray(sd["head_dist.weight"].T), sd["head_dist.bias"]
     return out

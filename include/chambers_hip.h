@@ -106,9 +106,10 @@ int chb_dropout_mask(uint8_t* out, int64_t n, float rate, uint32_t key, void* st
  *  DGELU: aux is that saved derivative.
  *  RESID: resid fp32 [M,ld_resid] (may alias C); dropout (rate,key) on acc+bias, element
  *         index row*N+col.
- *  PATCH: rows are (image b, patch p) = row / period, row % period; written to row
- *         b*(period+1)+1+p of C; resid = positional table fp32 [period+1, ld_resid];
- *         dropout element index out_row*N+col.
+ *  PATCH: rows are (image b, patch p) = row / n, row % n with n = period & 0xffffff patches per image and
+ *         s = 1 + ((period >> 24) & 15) special tokens in front of them (1: class token, vision_transformer.py:249-256;
+ *         2: class + distillation token, :340-357); written to row b*(n+s)+s+p of C; resid = positional table fp32
+ *         [n+s, ld_resid]; dropout element index out_row*N+col.
  * out_colsum (fp32 [N], optional): += column sums of C — the bias gradient of the layer that consumes C in the
  * backward chain (fused into the epilogue; caller zeroes it once per step).
  * K % 64 == 0; M, N arbitrary (edges masked); A/B/C 16-byte aligned rows. */
@@ -147,10 +148,18 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
  * layers/embedding.py:179-180,251-261; vision_transformer.py:249-261). x fp32 [B,N,D]. */
 int chb_cls_row(float* x, const float* cls, const float* pos, int B, int N, int D, float drop_rate, uint32_t drop_key,
                 void* stream);
+/* the same for any special-token row: x[b,row,:] = dropout(tok + pos[row]) — row 1 is the distillation token of
+ * DistilledVisionTransformer (ConcatEmbedding "add_dist_token", vision_transformer.py:340-347). */
+int chb_token_row(float* x, const float* tok, const float* pos, int B, int N, int D, int row, float drop_rate,
+                  uint32_t drop_key, void* stream);
 /* backward of embedding stage: dx fp32 [B,N,D] -> dpatch bf16 [B*(N-1), D] (masked), dpos fp32
  * [N,D] and dcls fp32 [D] (accumulated, caller zeroes). */
 int chb_embed_bwd(const float* dx, void* dpatch_bf16, float* dpos, float* dcls, int B, int N, int D, float drop_rate,
                   uint32_t drop_key, void* stream);
+/* the same with n_special tokens in front of the patches: dtok fp32 [n_special, D] (row 0 class, row 1 distillation
+ * token), dpatch bf16 [B*(N-n_special), D]. */
+int chb_embed_bwd_tokens(const float* dx, void* dpatch_bf16, float* dpos, float* dtok, int B, int N, int D, int n_special,
+                         float drop_rate, uint32_t drop_key, void* stream);
 /* dz = dy * keep * 1/(1-rate) as bf16 (backward of keras Dropout ahead of a GEMM). */
 int chb_dropout_bwd_bf16(const float* dy, int64_t ld, void* dz_bf16, int M, int N, float drop_rate, uint32_t drop_key,
                          void* stream);

@@ -146,8 +146,11 @@ def vit_forward(p, images, cfg, keys=None, bf16=False, return_tokens=False):
     x = patch_embed(images, p["patch_embeddings/embedding/kernel"],
                     p["patch_embeddings/embedding/bias"], cfg["patch_size"], bf16)
     b = x.shape[0]
+    distilled = "add_dist_token/embeddings" in p         # DistilledVisionTransformer, vision_transformer.py:340-357
+    if distilled:
+        x = torch.cat([p["add_dist_token/embeddings"].unsqueeze(0).expand(b, -1, -1), x], dim=1)
     cls = p["add_cls_token/embeddings"].unsqueeze(0).expand(b, -1, -1)
-    x = torch.cat([cls, x], dim=1)                       # ConcatEmbedding side="left"
+    x = torch.cat([cls, x], dim=1)                       # ConcatEmbedding side="left": [cls, (dist,) patches]
     x = x + p["pos_embedding/embeddings"]                # LearnedEmbedding1D
     x = _drop(x, rate, keys.get(SITE_EMBED))
     for i in range(cfg["n_encoder_layers"]):
@@ -156,6 +159,7 @@ def vit_forward(p, images, cfg, keys=None, bf16=False, return_tokens=False):
                    cfg.get("norm_epsilon", 1e-6))
     if return_tokens:
         return x
+    x_dist = x[:, 1, :] if distilled else None           # "dist_embedding": Cropping1D((1, N-2)), :375-381
     pooling = cfg.get("pooling", "cls")
     if pooling in ("avg", "max", "sum"):
         x = _bf(x, bf16)     # the build pools the bf16 LayerNorm output (fp32 reduction)
@@ -171,6 +175,12 @@ def vit_forward(p, images, cfg, keys=None, bf16=False, return_tokens=False):
         x = torch.tanh(torch.matmul(_bf(x, bf16), _bf(p["feature/kernel"], bf16)) + p["feature/bias"])
     if "predictions/kernel" in p:
         x = torch.matmul(_bf(x, bf16), _bf(p["predictions/kernel"], bf16)) + p["predictions/bias"]
+    if distilled:
+        if "predictions_dist/kernel" in p:
+            x_dist = torch.matmul(_bf(x_dist, bf16), _bf(p["predictions_dist/kernel"], bf16)) + p["predictions_dist/bias"]
+        if cfg.get("return_dist_token", True):           # :392-395
+            return x, x_dist
+        return (x + x_dist) / 2.0                        # keras Average
     return x
 
 

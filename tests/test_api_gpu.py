@@ -162,3 +162,48 @@ def test_compile_with_adamw_regex_and_warmup_schedule():
     l1 = m.train_step(x, y)        # lr(1) = 2.5e-4 now moves everything
     m.sync_from_engine(4)
     assert not np.array_equal(m.keras_weights()["predictions/bias"], before["predictions/bias"]) and torch.isfinite(l1).all()
+
+
+def test_deit_builder_outputs_and_timm_import():
+    """DeiTS16-style builder (vision_transformer.py:583-617) at a reduced width: layer names, weight count, the [cls, dist] output
+    pair against the oracle, and import of a timm-layout distilled state dict (dist_token, head_dist)."""
+    from chambers_amd.models.backbones.vision_transformer import DeiTS16, DistilledVisionTransformer
+    with pytest.raises(RuntimeError):
+        DeiTS16()                                              # default weights tag needs the network
+    with pytest.raises(ValueError):
+        DistilledVisionTransformer(16, 128, 1, 2, 256, input_shape=(32, 32, 3), weights=None)   # reference default pooling=None
+    m = DistilledVisionTransformer(16, 128, 2, 2, 256, input_shape=(64, 48, 3), weights=None, pooling="cls", classes=10)
+    names = [l.name for l in m.layers]
+    assert names[:4] == ["patch_embeddings", "add_dist_token", "add_cls_token", "pos_embedding"] and names[-2:] == ["predictions", "predictions_dist"]
+    _randomize(m, 11)
+    g = np.random.Generator(np.random.PCG64(2))
+    images = g.integers(0, 256, size=(3, 64, 48, 3), dtype=np.uint8)
+    out = m(torch.as_tensor(images, device="cuda"))
+    kw = {k: torch.tensor(v) for k, v in m.keras_weights().items()}
+    ref = vit_ref.vit_forward(kw, torch.from_numpy(A.imagenet_normalize(images, "tf")), m.cfg.as_oracle_cfg(), bf16=True)
+    assert isinstance(out, list) and len(out) == 2
+    for o, r in zip(out, ref):
+        assert tuple(o.shape) == (3, 10) and rel_l2(o, r) < 4e-3
+    avg = DistilledVisionTransformer(16, 128, 2, 2, 256, input_shape=(64, 48, 3), weights=None, pooling="cls", classes=10,
+                                     return_dist_token=False)
+    avg.set_weights(m.get_weights())
+    assert torch.allclose(avg(torch.as_tensor(images, device="cuda")), (out[0] + out[1]) / 2, atol=1e-6)
+    # timm-layout distilled checkpoint -> same predictions as assigning the equivalent Keras arrays
+    d, heads, ff, L, p_ = 128, 2, 256, 2, 16
+    r = lambda *s_: (g.normal(0, 0.05, size=s_)).astype(np.float32)   # noqa: E731
+    sd = {"patch_embed.proj.weight": r(d, 3, p_, p_), "patch_embed.proj.bias": r(d), "cls_token": r(1, 1, d), "dist_token": r(1, 1, d),
+          "pos_embed": r(1, 14, d), "norm.weight": 1 + r(d), "norm.bias": r(d), "head.weight": r(10, d), "head.bias": r(10),
+          "head_dist.weight": r(10, d), "head_dist.bias": r(10)}
+    for i in range(L):
+        t = "blocks.%d." % i
+        sd.update({t + "norm1.weight": 1 + r(d), t + "norm1.bias": r(d), t + "attn.qkv.weight": r(3 * d, d), t + "attn.qkv.bias": r(3 * d),
+                   t + "attn.proj.weight": r(d, d), t + "attn.proj.bias": r(d), t + "norm2.weight": 1 + r(d), t + "norm2.bias": r(d),
+                   t + "mlp.fc1.weight": r(ff, d), t + "mlp.fc1.bias": r(ff), t + "mlp.fc2.weight": r(d, ff), t + "mlp.fc2.bias": r(d)})
+    m.load_timm_state_dict(sd)
+    kw2 = m.keras_weights()
+    np.testing.assert_array_equal(kw2["add_dist_token/embeddings"], sd["dist_token"].reshape(1, d))
+    np.testing.assert_array_equal(kw2["predictions_dist/kernel"], sd["head_dist.weight"].T)
+    out2 = m(torch.as_tensor(images, device="cuda"))
+    ref2 = vit_ref.vit_forward({k: torch.tensor(v) for k, v in kw2.items()}, torch.from_numpy(A.imagenet_normalize(images, "tf")),
+                               m.cfg.as_oracle_cfg(), bf16=True)
+    assert rel_l2(out2[1], ref2[1]) < 4e-3

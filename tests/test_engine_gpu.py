@@ -242,6 +242,37 @@ def test_vit_large_width_train_step_config4():
     _grad_check(eng, kw, p, tol=4e-2)   # w_query / w_key gradients sum bf16-rounded dS over 16 heads at batch 2: ~3e-2
 
 
+@pytest.mark.parametrize("pooling,include_top,return_dist", [("cls", True, True), ("avg", True, False), ("cls", False, True)])
+def test_distilled_variant_matches_oracle(pooling, include_top, return_dist):
+    """DistilledVisionTransformer (vision_transformer.py:295-400): [cls, dist, patches] sequence, `predictions` on the pooled class
+    embedding and `predictions_dist` on sequence row 1; outputs as a pair or averaged; every gradient through backward(doutput)."""
+    cfg = _cfg(pooling=pooling, include_top=include_top, distilled=True, return_dist_token=return_dist)
+    assert cfg.n_tokens == 12 + 2
+    bsz, seed = 4, 17
+    eng, kw, images, _ = _setup(cfg, bsz, training=True, seed=seed)
+    assert "add_dist_token/embeddings" in kw and ("predictions_dist/kernel" in kw) == include_top
+    out = eng.forward(torch.as_tensor(images, device="cuda"), training=True)
+    x = torch.from_numpy(A.imagenet_normalize(images, "tf"))
+    p = _oracle_params(kw, requires_grad=True)
+    ref = vit_ref.vit_forward(p, x, cfg.as_oracle_cfg(), keys=_keys(cfg, seed, 0), bf16=True)
+    gen = torch.Generator().manual_seed(23)
+    if return_dist:
+        assert isinstance(out, tuple) and len(out) == 2
+        for o, r in zip(out, ref):
+            assert tuple(o.shape) == tuple(r.shape) and rel_l2(o.float().cpu(), r.detach()) < 4e-3
+        douts = [torch.randn(r.shape, generator=gen) for r in ref]
+        eng.backward(tuple(t.cuda() for t in douts))
+        (ref[0] * douts[0]).sum().add((ref[1] * douts[1]).sum()).backward()
+    else:
+        assert rel_l2(out.float().cpu(), ref.detach()) < 4e-3
+        dout = torch.randn(ref.shape, generator=gen)
+        eng.backward(dout.cuda())
+        ref.backward(dout)
+    _grad_check(eng, kw, p)
+    with pytest.raises(ValueError):
+        eng.train_step(torch.as_tensor(images, device="cuda"), torch.zeros(bsz, dtype=torch.long, device="cuda"))
+
+
 def test_vit_tiny_224_forward_config1():
     """BASELINE config 1: ViT-Ti/16 forward on 8x224x224x3 (the reference's CPU-runnable case)."""
     cfg = _cfg(patch_dim=192, n_heads=3, ff_dim=768, n_encoder_layers=12, image_size=(224, 224), classes=1000, dropout_rate=0.1)

@@ -181,3 +181,25 @@ def test_rotate_transform_host_side_matches_oracle():
     for deg, neg, h, w in ((27.0, False, 224, 224), (27.0, True, 37, 53), (0.0, False, 5, 9), (90.0, True, 64, 48)):
         rad = deg * math.pi / 180.0
         np.testing.assert_array_equal(Rotate.transform_for(-rad if neg else rad, h, w), A.rotate_transform(deg, neg, h, w))
+
+
+def test_distilled_parameter_table_and_weight_roundtrip():
+    """DistilledVisionTransformer weights (vision_transformer.py:340-357,383-390): add_dist_token / predictions_dist exist, the two
+    special tokens share one internal [2, D] tensor, and the Keras <-> internal conversion round-trips exactly."""
+    from chambers_amd.engine import (ViTConfig, build_param_table, init_keras_weights, internal_to_keras, keras_to_internal,
+                                     keras_variable_names)
+    cfg = ViTConfig(16, 128, 2, 2, 256, image_size=(32, 32), classes=10, distilled=True)
+    assert cfg.n_special == 2 and cfg.n_tokens == 4 + 2
+    kw = init_keras_weights(cfg)
+    assert kw["add_dist_token/embeddings"].shape == (1, 128) and kw["predictions_dist/kernel"].shape == (128, 10)
+    iw = keras_to_internal(kw, cfg)
+    assert iw["add_cls_token/embeddings"].shape == (2, 128)
+    back = internal_to_keras(iw, cfg)
+    assert set(back) == set(kw)
+    for k in kw:
+        np.testing.assert_array_equal(back[k], kw[k])
+    specs, _, buckets = build_param_table(cfg)
+    assert set(keras_variable_names(cfg)) == {s.name for s in specs} and len(buckets) == 2 + 2
+    assert keras_variable_names(cfg)["add_cls_token/embeddings"] == ["add_cls_token/embeddings:0", "add_dist_token/embeddings:0"]
+    with pytest.raises(ValueError):
+        ViTConfig(16, 128, 2, 2, 256, distilled=True, feature_dim=64)
