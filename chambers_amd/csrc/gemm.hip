@@ -913,7 +913,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt128_kernel(GemmParams p) {
 }
 
 // ---- TN (wgrad), 256x256 output tile, one (tile, M-split) work item per 512-thread workgroup ----
-// Same 4-phase / half-tile ring as gemm_nt256_kernel; the operand half-tiles are [64 m][128 cols]
+// Four phases of 16 MFMAs over the same half-tile ring as gemm_nt256_kernel (one barrier per phase, plus the one that follows
+// the counted wait of phase 4); the operand half-tiles are [64 m][128 cols]
 // (256-byte rows) and every fragment is a pair of transposed LDS reads.  The reduction axis is the
 // long token axis M, split over workgroups so that tiles x splits ~ number of CUs; partial tiles are
 // added into dW with fp32 atomics issued as full 256-byte rows (staged through LDS).
@@ -1012,9 +1013,8 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[a] + ks * 32 * 128);
         if (have1) stage_half_tn(p.X, p.ldx, m1, k0, p.Kd, nring + 0 * 8192, wave, lane);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
+        __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1032,9 +1032,8 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) y1[b][ks] = frag_tn_at(Ys + yo[2 + b] + ks * 32 * 128);
         if (have1) stage_half_tn(p.X, p.ldx, m1, k0 + 128, p.Kd, nring + 1 * 8192, wave, lane);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
+        __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1052,9 +1051,8 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[4 + a] + ks * 32 * 128);
         if (have2) stage_half_tn(p.Y, p.ldy, m2, n0, p.Nd, ring + 2 * 8192, wave, lane);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
+        __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
