@@ -913,8 +913,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt128_kernel(GemmParams p) {
 }
 
 // ---- TN (wgrad), 256x256 output tile, one (tile, M-split) work item per 512-thread workgroup ----
-// Four phases of 16 MFMAs over the same half-tile ring as gemm_nt256_kernel (one barrier per phase, plus the one that follows
-// the counted wait of phase 4); the operand half-tiles are [64 m][128 cols]
+// Four phases of 16 MFMAs over the same half-tile ring as gemm_nt256_kernel with TWO barriers per K-tile: after phase 2 (every
+// wave has read this ring's dY slots, which phases 3/4 restage) and after the counted wait of phase 4 (step s+1 has landed; every
+// wave has read this ring's X slots, which the next step restages).  Between them the waves drift by up to two phases, so one
+// wave's transposed reads overlap another's MFMAs.  The operand half-tiles are [64 m][128 cols]
 // (256-byte rows) and every fragment is a pair of transposed LDS reads.  The reduction axis is the
 // long token axis M, split over workgroups so that tiles x splits ~ number of CUs; partial tiles are
 // added into dW with fp32 atomics issued as full 256-byte rows (staged through LDS).
@@ -1024,7 +1026,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][ks], xf[a][ks], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        // (no barrier: phase 2 restages the OTHER ring's X slots and reads this ring's dY slots, nothing phase 1 still reads)
 
         // phase 2: (kd 0-63, nd 32-63)
 #pragma unroll
@@ -1062,7 +1064,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
                 for (int b = 0; b < 2; ++b) acc[4 + a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][ks], xf[a][ks], acc[4 + a][2 + b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        // (no barrier: phase 4 restages the dY slot whose readers all passed the barrier after phase 2)
 
         // phase 4: (kd 64-127, nd 0-31); retire step s+1's loads
         if (have2) {
@@ -1082,7 +1084,8 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
                 for (int b = 0; b < 2; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][ks], xf[a][ks], acc[4 + a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        // (no barrier: the next step's restaging of this ring's X slots is ordered by the barrier after the counted wait above —
+        //  every wave completed its phase-3 reads before reaching it)
     }
 
     // acc[a][b][r]: kd = k0 + wk*128 + a*16 + i, nd = n0 + wn*64 + b*16 + 4g + r.  Stage one 16(kd) x 64(nd) tile row
