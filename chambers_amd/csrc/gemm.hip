@@ -213,17 +213,15 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmParams p) {
 // ---- NT, persistent 256x256 tiles -------------------------------------------------------------
 // One 512-thread workgroup per CU (8 waves = 2(M) x 4(N), 128x64 outputs per wave) walks a list
 // of 256x256 output tiles.  Each 64-deep K-tile is four 16 KiB half-tiles (A rows 0-127 / 128-255,
-// B rows 0-127 / 128-255) in a 2-deep LDS ring (128 KiB).  A K-tile is computed in four phases of
-// 16 MFMAs (one 64x32 quadrant of the wave's output each); every phase also issues the two
-// global_load_lds of ONE half-tile of a later K-tile, so loads stay in flight across barriers and
-// across output-tile boundaries (the epilogue of tile i overlaps the loads of tile i+1):
-//   phase 1: read A(rows 0-63 of the wave), B(cols 0-31)   | stage A-half0 of step s+1
-//   phase 2: read B(cols 32-63)                            | stage A-half1 of step s+1
-//   phase 3: read A(rows 64-127)                           | stage B-half0 of step s+2
-//   phase 4: (B cols 0-31 kept in registers)               | stage B-half1 of step s+2, vmcnt(4)
-// The counted wait in phase 4 retires everything but the two B half-tiles of step s+2, i.e. all of
-// step s+1, which is first read one phase later (after the barriers).  A ring slot is restaged only
-// after the barrier that follows its last ds_read (B: end of phase 2, A: end of phase 3).
+// B rows 0-127 / 128-255) in a 2-deep LDS ring (128 KiB).  A K-tile is computed in two phases of
+// 32 MFMAs (rows 0-63 / 64-127 of the wave's output) with ONE barrier per K-tile; the loads of later
+// K-tiles stay in flight across it and across output-tile boundaries (the epilogue of tile i overlaps
+// the loads of tile i+1):
+//   phase 1: stage A of step s+1 into the other ring | read B (all 64 columns) and A rows 0-63 | MFMAs
+//   phase 2: read A rows 64-127 | vmcnt(0) + barrier | stage B of step s+2 into THIS ring | MFMAs
+// The barrier follows every ds_read of this ring (each wave waits lgkmcnt(0) before its MFMAs), so the B
+// slots can be restaged right behind it and the A slots in phase 1 of the next step; the wait in front
+// of it retires step s+1 (A issued one phase earlier, B one step earlier), first read after the MFMAs.
 // Epilogue of the persistent kernel: the wave's 128x64 fp32 accumulators go through a wave-private
 // 4 KiB LDS scratch, one 16x64 MFMA tile row at a time, and come back row-major (lane = 4 rows x 16
 // chunks of 4 columns), so that EVERY global access of the epilogue (residual / saved pre-activation
@@ -498,7 +496,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[a][ks] = *reinterpret_cast<const bf16x8_t*>(As + (ks ? a_off1 : a_off0) + a * 16 * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // every wave has consumed this step's B half-tiles
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -510,20 +507,21 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---------------- phase 2: rows 64-127 (32 MFMAs).  This ring's B slots are free: stage step s+2 into them.
-        if (cb.valid) {
-            stage_half(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, ring + 2 * 8192, wave, lane);
-            stage_half(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, ring + 3 * 8192, wave, lane);
-        }
+        // ---------------- phase 2: rows 64-127 (32 MFMAs).  No barrier separates the phases: the one below orders every read of
+        // this ring (B and A rows 0-63 in phase 1, A rows 64-127 here) before the restaging that follows it.
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[a][ks] = *reinterpret_cast<const bf16x8_t*>(As + (ks ? a_off1 : a_off0) + (64 + a * 16) * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // retire everything but the B half-tiles of step s+2: all of step s+1 has landed when the barrier opens
-        if (cb.valid) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A half-tiles
+        // all of step s+1 (A issued in phase 1 of this step, B after the previous step's barrier) has landed when the barrier opens
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A and B half-tiles; step s+1 has landed
+        __builtin_amdgcn_sched_barrier(0);
+        if (cb.valid) {                        // this ring's B slots are free now: step s+2 goes into them
+            stage_half(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, ring + 2 * 8192, wave, lane);
+            stage_half(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, ring + 3 * 8192, wave, lane);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
