@@ -136,7 +136,9 @@ int chb_layernorm_bwd(const void* dy_bf16, const float* x, int64_t x_stride, con
 
 /* MultiHeadAttention core (layers/attention.py:7-23,113-125): softmax(QK^T/sqrt(hd)) with
  * dropout on the probabilities, times V.  qkv bf16 [B*N, 3*H*hd] = [Q heads | K heads | V heads];
- * o bf16 [B*N, H*hd]; lse fp32 [B,H,N]. hd == 64. Dropout element index ((b*H+h)*N+q)*N+k. */
+ * o bf16 [B*N, H*hd]; lse fp32 [B,H,N]. hd == 64; any N with B*H*N*N < 2^32 (the dropout element index
+ * ((b*H+h)*N+q)*N+k is 32-bit): N <= 224 runs with the head resident in LDS, longer sequences (577 tokens at
+ * 384x384) through the streaming forward and the two-pass backward. */
 int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate,
                       uint32_t drop_key, void* stream);
 /* dbias_qkv (fp32 [3*H*hd], optional): += column sums of dqkv (bias gradient of the fused QKV projection). */
