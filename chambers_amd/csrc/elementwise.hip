@@ -33,17 +33,21 @@ __global__ void cls_row_kernel(float* x, const float* cls, const float* pos, int
     }
 }
 
-// thread = (token t, 4 columns); loops over the batch: dpos[t] = sum_b dz[b,t], dtok[t] = dpos[t] for the ns special tokens,
-// dpatch[b, t-ns] = bf16(dz[b,t]) for t >= ns, with dz = dx * keep * scale.
+// thread = (token t, 4 columns) x a slice of the batch (blockIdx.y): dpos[t] += sum_b dz[b,t], dtok[t] likewise for the ns
+// special tokens, dpatch[b, t-ns] = bf16(dz[b,t]) for t >= ns, with dz = dx * keep * scale.  The batch is sliced so that the
+// grid fills the chip (one thread per (token, column quad) alone is ~150 waves); the slices meet in fp32 atomics on buffers
+// the caller zeroes once per step.
 __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dpatch, float* __restrict__ dpos,
                                                         float* __restrict__ dcls, int B, int N, int D, int ns, float scale, uint32_t thr,
                                                         uint32_t key) {
     const int dq = D >> 2;
     const int64_t total = (int64_t)N * dq;
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(idx / dq), d = (int)(idx - (int64_t)t * dq) * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int b = 0; b < B; ++b) {
+        for (int b = b0; b < b1; ++b) {
             const int64_t e = ((int64_t)b * N + t) * D + d;
             float4 v = *reinterpret_cast<const float4*>(dx + e);
             if (thr) {
@@ -61,8 +65,12 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict_
                 *reinterpret_cast<uint2*>(dpatch + ((int64_t)b * (N - ns) + (t - ns)) * D + d) = o;
             }
         }
-        *reinterpret_cast<float4*>(dpos + (int64_t)t * D + d) = acc;
-        if (t < ns) *reinterpret_cast<float4*>(dcls + (int64_t)t * D + d) = acc;   // special tokens: class (row 0), distillation (row 1)
+        float* pp = dpos + (int64_t)t * D + d;
+        atomicAdd(pp + 0, acc.x); atomicAdd(pp + 1, acc.y); atomicAdd(pp + 2, acc.z); atomicAdd(pp + 3, acc.w);
+        if (t < ns) {   // special tokens: class (row 0), distillation (row 1)
+            float* pc = dcls + (int64_t)t * D + d;
+            atomicAdd(pc + 0, acc.x); atomicAdd(pc + 1, acc.y); atomicAdd(pc + 2, acc.z); atomicAdd(pc + 3, acc.w);
+        }
     }
 }
 
@@ -303,7 +311,11 @@ int chb_embed_bwd_tokens(const float* dx, void* dpatch, float* dpos, float* dtok
     if (!dx || !dpatch || !dpos || !dtok || B < 0 || n_special < 1 || N <= n_special || D <= 0 || (D & 3) || drop_rate < 0.f ||
         drop_rate >= 1.f)
         return CHB_EINVAL;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((int64_t)N * (D / 4))), dim3(256), 0, (hipStream_t)stream, dx, (bf16_t*)dpatch,
+    if (B == 0) return CHB_OK;
+    const int gx = grid_for((int64_t)N * (D / 4));
+    int slices = 2048 / gx;                       // ~2048 workgroups in total
+    slices = slices < 1 ? 1 : (slices > B ? B : slices);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(gx, slices), dim3(256), 0, (hipStream_t)stream, dx, (bf16_t*)dpatch,
                        dpos, dtok, B, N, D, n_special, 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u,
                        drop_key);
     CHB_LAUNCH_CHECK();
