@@ -17,6 +17,7 @@ STAMP_PATH = os.path.join(CSRC, ".build_stamp")
 # per-file extra flags: augment.hip must round after every float op like the TF CPU kernels
 SOURCES = {
     "augment.hip": ["-ffp-contract=off"],
+    "imageio.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
     "layernorm.hip": [],
     "attention.hip": [],

@@ -50,6 +50,9 @@ PROTOTYPES = {
     "chb_colsum_bf16": [P, c_int64, P, c_int, c_int, P],
     "chb_softmax_ce": [P, c_int64, P, P, P, c_int64, c_int, c_int, c_float, P],
     "chb_pool_tokens": [P, P, P, c_int, c_int, c_int, c_int, P],
+    "chb_resize": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "chb_crop_flip": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P],
+    "chb_rescale": [P, c_int, P, c_int64, c_float, c_float, P],
     "chb_pool_tokens_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
     "chb_tanh_fwd": [P, P, c_int64, P],
     "chb_tanh_bwd": [P, P, P, c_int64, P],

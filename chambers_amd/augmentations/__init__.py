@@ -1,6 +1,15 @@
 """chambers.augmentations namespace (reference: chambers/augmentations/__init__.py:14-39).
-The Keras preprocessing layers the reference re-exports (:1-13) are not chambers code and are
-out of scope of this build."""
+Of the Keras preprocessing layers the reference re-exports (:1-13), the input-side ones of SURVEY §8f rank 3 are built
+(Resizing, CenterCrop, RandomCrop, RandomFlip, Rescaling — .preprocessing); RandomRotation / RandomZoom / RandomTranslation /
+RandomContrast / RandomHeight / RandomWidth are not."""
+from .preprocessing import (  # noqa: F401
+    CenterCrop,
+    RandomCrop,
+    RandomFlip,
+    Rescaling,
+    Resizing,
+    ResizingMinMax,
+)
 from .image_augmentations import (  # noqa: F401
     ImageNetNormalization,
     RandomChoice,

@@ -140,6 +140,66 @@ def dropout_mask(n, rate, key, device="cuda"):
     return out
 
 
+# ------------------------------------------------------------------ input side
+def _nhwc(x):
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D NHWC batch, got shape %s" % (tuple(x.shape),))
+    if x.dtype not in (torch.uint8, torch.float32):
+        raise ValueError("expected uint8 or float32 images, got %s" % (x.dtype,))
+    _lib.require_gpu(x)
+    return x.contiguous()
+
+
+def resize(x, out_h, out_w, method="bilinear"):
+    """tf.image.resize (half-pixel centres, no antialias): bilinear -> float32, nearest -> dtype of x."""
+    x = _nhwc(x)
+    if method not in ("bilinear", "nearest"):
+        raise ValueError("unsupported interpolation %r (bilinear, nearest)" % (method,))
+    b, h, w, c = x.shape
+    out = torch.empty((b, int(out_h), int(out_w), c), dtype=torch.float32 if method == "bilinear" else x.dtype, device=x.device)
+    _lib.call("chb_resize", _lib.ptr(x), 0 if x.dtype == torch.uint8 else 1, _lib.ptr(out), b, h, w, c, int(out_h), int(out_w),
+              0 if method == "bilinear" else 1, _s())
+    return out
+
+
+def crop_flip(x, out_h, out_w, offsets=None, flips=None):
+    """Window gather with optional per-image flips.  offsets: (y, x) tuple for the whole batch, or an int32 [B,2] array /
+    tensor; flips: uint8 [B] (bit 0 left-right, bit 1 up-down) or None."""
+    x = _nhwc(x)
+    b, h, w, c = x.shape
+    out = torch.empty((b, int(out_h), int(out_w), c), dtype=x.dtype, device=x.device)
+    oy0 = ox0 = 0
+    off_t = None
+    per_image = 0
+    if offsets is not None:
+        arr = offsets if isinstance(offsets, torch.Tensor) else np.asarray(offsets, dtype=np.int32)
+        if tuple(arr.shape) == (2,):
+            oy0, ox0 = int(arr[0]), int(arr[1])
+        else:
+            if isinstance(arr, np.ndarray):
+                if arr.shape != (b, 2) or arr.min() < 0 or (arr[:, 0] + out_h).max() > h or (arr[:, 1] + out_w).max() > w:
+                    raise ValueError("crop windows must lie inside the image")
+                arr = torch.as_tensor(arr, device=x.device)
+            off_t = arr.to(torch.int32).contiguous()
+            per_image = 1
+    fl_t = None
+    if flips is not None:
+        fl_t = (flips if isinstance(flips, torch.Tensor) else torch.as_tensor(np.asarray(flips, dtype=np.uint8), device=x.device)).to(torch.uint8).contiguous()
+    _lib.call("chb_crop_flip", _lib.ptr(x), _lib.ptr(out), b, h, w, c * x.element_size(), int(out_h), int(out_w),
+              _lib.ptr(off_t) if off_t is not None else None, per_image, oy0, ox0, _lib.ptr(fl_t) if fl_t is not None else None, _s())
+    return out
+
+
+def rescale(x, scale, offset=0.0):
+    if x.dtype not in (torch.uint8, torch.float32):
+        raise ValueError("expected uint8 or float32, got %s" % (x.dtype,))
+    _lib.require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.call("chb_rescale", _lib.ptr(x), 0 if x.dtype == torch.uint8 else 1, _lib.ptr(out), x.numel(), float(scale), float(offset), _s())
+    return out
+
+
 # ------------------------------------------------------------------ ViT block
 def gemm_nt(a, b, out, m=None, bias=None, epilogue=EPI_NONE, aux=None, resid=None, period=0, drop_rate=0.0, drop_key=0, colsum=None):
     """out[M,N] = epi(a[M,K] . b[N,K]^T); a, b bf16 2-D (row stride taken from the tensors)."""

@@ -145,6 +145,23 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
 int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N,
                       int H, int hd, float drop_rate, uint32_t drop_key, float* dbias_qkv, void* stream);
 
+/* ---------------------------------------------------------------- input side */
+#define CHB_DT_U8 0
+#define CHB_DT_F32 1
+#define CHB_RESIZE_BILINEAR 0
+#define CHB_RESIZE_NEAREST 1
+/* tf.image.resize as keras `Resizing` and chambers `ResizingMinMax` call it (augmentations/__init__.py:11,
+ * image_augmentations.py:686-748): NHWC in (uint8 or fp32) -> [B,OH,OW,C]; bilinear writes fp32, nearest the input
+ * dtype; half-pixel centres, no antialias (TF2). */
+int chb_resize(const void* in, int in_dtype, void* out, int B, int H, int W, int C, int OH, int OW, int method, void* stream);
+/* CenterCrop / RandomCrop / RandomFlip (augmentations/__init__.py:1-13) as one gather of whole pixels of
+ * `pixel_bytes` bytes: window offset (y, x) = offsets_dev[b] (per_image) / offsets_dev[0] / (oy0, ox0) when NULL;
+ * flips_dev[b] bit 0 = left-right, bit 1 = up-down inside the window (NULL = none). */
+int chb_crop_flip(const void* in, void* out, int B, int H, int W, int pixel_bytes, int OH, int OW, const int32_t* offsets_dev,
+                  int per_image, int oy0, int ox0, const uint8_t* flips_dev, void* stream);
+/* keras `Rescaling`: out fp32 [n] = float(in) * scale + offset. */
+int chb_rescale(const void* in, int in_dtype, float* out, int64_t n, float scale, float offset, void* stream);
+
 /* ---------------------------------------------------------------- glue around the block */
 /* x[b,0,:] = dropout(cls + pos[0]) (ConcatEmbedding + LearnedEmbedding1D + Dropout,
  * layers/embedding.py:179-180,251-261; vision_transformer.py:249-261). x fp32 [B,N,D]. */

@@ -445,3 +445,80 @@ def auto_augment(x, decision):
             x = apply_op(x, name, magnitude_to_kwargs(name, mag),
                          negate=decision["negate"][j])
     return x
+
+
+# --------------------------------------------------------------------------- #
+# input side: keras preprocessing layers re-exported by chambers.augmentations
+# (augmentations/__init__.py:1-13) and chambers' ResizingMinMax (:686-748).
+# tf.image.resize / Keras layer behaviour is upstream restated (TF 2.6).
+# --------------------------------------------------------------------------- #
+def resize(x, out_h, out_w, method="bilinear"):
+    """tf.image.resize(images, [out_h, out_w], method) with TF2 semantics (half-pixel centres, antialias=False).
+    bilinear -> float32, arithmetic order of the CPU kernel (compute_interpolation_weights + compute_lerp);
+    nearest -> input dtype, index min(floor((o + 0.5) * scale), size - 1)."""
+    b, h, w, c = x.shape
+    sy, sx = F32(h) / F32(out_h), F32(w) / F32(out_w)
+    oy = np.arange(out_h, dtype=F32)
+    ox = np.arange(out_w, dtype=F32)
+    if method == "nearest":
+        iy = np.minimum(np.floor((oy + F32(0.5)) * sy).astype(np.int64), h - 1)
+        ix = np.minimum(np.floor((ox + F32(0.5)) * sx).astype(np.int64), w - 1)
+        return np.ascontiguousarray(x[:, iy][:, :, ix])
+    if method != "bilinear":
+        raise ValueError("unsupported interpolation %r" % (method,))
+    fy = ((oy + F32(0.5)) * sy - F32(0.5)).astype(F32)
+    fx = ((ox + F32(0.5)) * sx - F32(0.5)).astype(F32)
+    fy0, fx0 = np.floor(fy), np.floor(fx)
+    y0 = np.maximum(fy0.astype(np.int64), 0)
+    y1 = np.minimum(np.ceil(fy).astype(np.int64), h - 1)
+    x0 = np.maximum(fx0.astype(np.int64), 0)
+    x1 = np.minimum(np.ceil(fx).astype(np.int64), w - 1)
+    ty = (fy - fy0).astype(F32)[None, :, None, None]
+    tx = (fx - fx0).astype(F32)[None, None, :, None]
+    xf = x.astype(F32)
+    tl, tr = xf[:, y0][:, :, x0], xf[:, y0][:, :, x1]
+    bl, br = xf[:, y1][:, :, x0], xf[:, y1][:, :, x1]
+    top = (tl + ((tr - tl) * tx).astype(F32)).astype(F32)
+    bot = (bl + ((br - bl) * tx).astype(F32)).astype(F32)
+    return (top + ((bot - top) * ty).astype(F32)).astype(F32)
+
+
+def resizing_minmax_size(height, width, min_side=None, max_side=None):
+    """ResizingMinMax.call size arithmetic, image_augmentations.py:712-731 (float32, truncating cast)."""
+    if min_side is None and max_side is None:
+        raise ValueError("Must specify either 'min_side' or 'max_side'.")
+    h, w = F32(height), F32(width)
+    if min_side is not None and max_side is not None:
+        scale = np.minimum(F32(max_side) / np.maximum(w, h), F32(min_side) / np.minimum(w, h))
+    elif min_side is not None:
+        scale = F32(min_side) / np.minimum(w, h)
+    else:
+        scale = F32(max_side) / np.maximum(w, h)
+    return int(F32(h * F32(scale))), int(F32(w * F32(scale)))
+
+
+def crop_flip(x, out_h, out_w, offsets, flips=None):
+    """CenterCrop / RandomCrop window + RandomFlip: offsets int [B,2] or [2] = (y, x); flips uint8 [B], bit 0 left-right,
+    bit 1 up-down (applied inside the window)."""
+    b = x.shape[0]
+    offsets = np.broadcast_to(np.asarray(offsets, dtype=np.int64).reshape(-1, 2), (b, 2))
+    out = np.empty((b, out_h, out_w) + x.shape[3:], dtype=x.dtype)
+    for n in range(b):
+        win = x[n, offsets[n, 0]:offsets[n, 0] + out_h, offsets[n, 1]:offsets[n, 1] + out_w]
+        f = 0 if flips is None else int(flips[n])
+        if f & 2:
+            win = win[::-1]
+        if f & 1:
+            win = win[:, ::-1]
+        out[n] = win
+    return out
+
+
+def center_crop_offsets(height, width, out_h, out_w):
+    """keras CenterCrop: start = int((size - target) / 2)."""
+    return int((height - out_h) / 2), int((width - out_w) / 2)
+
+
+def rescale(x, scale, offset=0.0):
+    """keras Rescaling: cast(x, float32) * scale + offset."""
+    return ((x.astype(F32) * F32(scale)).astype(F32) + F32(offset)).astype(F32)

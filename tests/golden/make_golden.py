@@ -32,6 +32,7 @@ AUG_CASES = [
     ("translatey2.5", "TranslateY", {"pixels": 2.5, "fill_value": 0}, False), ("rotate27", "Rotate", {"degrees": 27.0, "fill_value": 128}, False),
     ("rotate27neg", "Rotate", {"degrees": 27.0, "fill_value": 128}, True), ("cutout8", "CutOut", {"mask_size": 8, "constant_values": 128}, False),
 ]
+INPUT_SIDE_SIZE, INPUT_SIDE_OFFSET = (30, 36), (2, 1)
 IMAGE_SHAPES = {"a": (2, 20, 24, 3), "b": (3, 9, 10, 3)}    # W % 4 == 0 (vector paths) and a ragged shape (generic paths)
 NORM_KAT_IMG = np.array([[139, 186, 208, 200], [175, 201, 198, 200], [166, 191, 193, 195], [124, 155, 172, 151]], dtype=np.uint8)
 NORM_KAT = {   # reference-derived (test_image_augmentations.py:21-64), channel 0 of the broadcast grey image
@@ -63,6 +64,15 @@ def augment_fixture():
         out["autoaugment_p22_%s" % tag] = A.auto_augment(x, {"policy": 22, "apply": (True, True), "negate": (False, False)})
         for mode in ("tf", "torch", "caffe"):
             out["normalize_%s_%s" % (mode, tag)] = A.imagenet_normalize(x, mode)
+        # input side (Resizing / CenterCrop / RandomCrop / RandomFlip / Rescaling)
+        oh, ow = INPUT_SIDE_SIZE
+        out["resize_bilinear_%s" % tag] = A.resize(x, oh, ow, "bilinear")
+        out["resize_nearest_%s" % tag] = A.resize(x, oh, ow, "nearest")
+        ch, cw = shape[1] - 4, shape[2] - 2
+        out["centercrop_%s" % tag] = A.crop_flip(x, ch, cw, A.center_crop_offsets(shape[1], shape[2], ch, cw))
+        out["randomcrop_%s" % tag] = A.crop_flip(x, ch, cw, INPUT_SIDE_OFFSET)
+        out["flip_%s" % tag] = A.crop_flip(x, shape[1], shape[2], (0, 0), np.arange(shape[0], dtype=np.uint8) % 4)
+        out["rescale_%s" % tag] = A.rescale(x, 1.0 / 255.0, -0.5)
     kat = np.stack([NORM_KAT_IMG] * 3, axis=-1)[None]
     out["norm_kat_x"] = kat
     for mode in ("tf", "torch", "caffe"):

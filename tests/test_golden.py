@@ -94,6 +94,17 @@ def test_hip_augment_ops_match_golden(tag):
     for pol, negate in ((3, (False, True)), (22, (False, False))):
         out = aug.AutoAugment()(x, training=True, decision={"policy": pol, "apply": (True, True), "negate": negate})
         np.testing.assert_array_equal(out.cpu().numpy(), ref["autoaugment_p%d_%s" % (pol, tag)])
+    oh, ow = gen.INPUT_SIDE_SIZE
+    shape = ref["x_" + tag].shape
+    ch, cw = shape[1] - 4, shape[2] - 2
+    np.testing.assert_array_equal(aug.Resizing(oh, ow)(x).cpu().numpy(), ref["resize_bilinear_" + tag])
+    np.testing.assert_array_equal(aug.Resizing(oh, ow, interpolation="nearest")(x).cpu().numpy(), ref["resize_nearest_" + tag])
+    np.testing.assert_array_equal(aug.CenterCrop(ch, cw)(x).cpu().numpy(), ref["centercrop_" + tag])
+    np.testing.assert_array_equal(aug.RandomCrop(ch, cw)(x, training=True, offset=gen.INPUT_SIDE_OFFSET).cpu().numpy(), ref["randomcrop_" + tag])
+    bits = np.arange(shape[0]) % 4
+    flipped = aug.RandomFlip()(x, training=True, flip_horizontal=(bits & 1).astype(bool), flip_vertical=(bits >> 1).astype(bool))
+    np.testing.assert_array_equal(flipped.cpu().numpy(), ref["flip_" + tag])
+    np.testing.assert_array_equal(aug.Rescaling(1.0 / 255.0, offset=-0.5)(x).cpu().numpy(), ref["rescale_" + tag])
     for mode in ("tf", "torch", "caffe"):
         out = aug.ImageNetNormalization(mode)(x).cpu().numpy()
         np.testing.assert_array_equal(out, ref["normalize_%s_%s" % (mode, tag)], err_msg=mode)

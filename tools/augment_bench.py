@@ -10,6 +10,7 @@ B, H, W = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 224, 224
 x = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda")
 px = B * H * W * 3
 centers = torch.full((B, 2), 100, dtype=torch.int32, device="cuda")   # resident decisions: the H2D copy of a host array is not the kernel
+flip_bits = (torch.arange(B, device="cuda") % 2 == 0)   # resident decisions
 cases = [
     ("Invert", lambda: aug.Invert()(x), 2), ("Posterize", lambda: aug.Posterize(3)(x), 2), ("Solarize", lambda: aug.Solarize(230)(x), 2),
     ("SolarizeAdd", lambda: aug.SolarizeAdd(99)(x), 2), ("Brightness", lambda: aug.Brightness(1.72)(x), 2),
@@ -18,6 +19,12 @@ cases = [
     ("Rotate", lambda: aug.Rotate(27.0, fill_value=128)(x, negate=False), 2), ("CutOut", lambda: aug.CutOut(72, 128)(x, centers=centers), 2),
     ("AutoContrast", lambda: aug.AutoContrast()(x), 3), ("Equalize", lambda: aug.Equalize()(x), 3),
     ("Normalize_tf_f32", lambda: aug.ImageNetNormalization("tf")(x), 5), ("NormalizePatchify_bf16", lambda: K.normalize_patchify(x, 16, "tf"), 3),
+    # input side: algorithmic bytes = window read once + output written once, as multiples of the [B,224,224,3] uint8 batch
+    ("RandomFlip", lambda: aug.RandomFlip()(x, training=True, flip_horizontal=flip_bits, flip_vertical=flip_bits), 2),
+    ("RandomCrop_192", lambda: aug.RandomCrop(192, 192)(x, training=True, offset=(11, 13)), 2 * (192 * 192) / (224.0 * 224.0)),
+    ("Rescaling_f32", lambda: aug.Rescaling(1 / 255.0)(x), 5),
+    ("Resizing_224_to_256_bilinear_f32", lambda: aug.Resizing(256, 256)(x), 1 + 4 * (256 * 256) / (224.0 * 224.0)),
+    ("Resizing_224_to_160_nearest_u8", lambda: aug.Resizing(160, 160, interpolation="nearest")(x), 2 * (160 * 160) / (224.0 * 224.0)),
 ]
 out = {}
 REP = 20
