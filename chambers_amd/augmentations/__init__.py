@@ -10,28 +10,7 @@ from .preprocessing import (  # noqa: F401
     Resizing,
     ResizingMinMax,
 )
-from .image_augmentations import (  # noqa: F401
-    ImageNetNormalization,
-    RandomChoice,
-    RandomChance,
-    AutoContrast,
-    Equalize,
-    Invert,
-    Rotate,
-    Posterize,
-    Solarize,
-    SolarizeAdd,
-    Color,
-    Contrast,
-    Brightness,
-    Sharpness,
-    ShearX,
-    ShearY,
-    TranslateX,
-    TranslateY,
-    CutOut,
-)
-from .augmentation_schemes import (  # noqa: F401
-    AutoAugment,
-    RandAugment,
-)
+from .image_augmentations import (AutoContrast, Brightness, Color, Contrast, CutOut, Equalize, ImageNetNormalization, Invert,  # noqa: F401
+                                  Posterize, RandomChance, RandomChoice, Rotate, Sharpness, ShearX, ShearY, Solarize, SolarizeAdd,
+                                  TranslateX, TranslateY)
+from .augmentation_schemes import AutoAugment, RandAugment  # noqa: F401

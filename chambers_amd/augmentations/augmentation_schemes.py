@@ -17,34 +17,45 @@ _FILL_MODE = "constant"
 _FILL_VALUE = 128
 _MAX_MAGNITUDE = 10.0
 
-_AUTO_AUGMENT_POLICY_V0 = [
-    # [(Transform, Probability, Magnitude), (Transform, Probability, Magnitude)]
-    [("Equalize", 0.8, None), ("ShearY", 0.8, 4)],
-    [("Color", 0.4, 9), ("Equalize", 0.6, None)],
-    [("Color", 0.4, 1), ("Rotate", 0.6, 8)],
-    [("Solarize", 0.8, 3), ("Equalize", 0.4, 7)],
-    [("Solarize", 0.4, 2), ("Solarize", 0.6, 2)],
-    [("Color", 0.2, 0), ("Equalize", 0.8, None)],
-    [("Equalize", 0.4, None), ("SolarizeAdd", 0.8, 3)],
-    [("ShearX", 0.2, 9), ("Rotate", 0.6, 8)],
-    [("Color", 0.6, 1), ("Equalize", 1.0, None)],
-    [("Invert", 0.4, None), ("Rotate", 0.6, 0)],
-    [("Equalize", 1.0, None), ("ShearY", 0.6, 3)],
-    [("Color", 0.4, 7), ("Equalize", 0.6, None)],
-    [("Posterize", 0.4, 6), ("AutoContrast", 0.4, None)],
-    [("Solarize", 0.6, 8), ("Color", 0.6, 9)],
-    [("Solarize", 0.2, 4), ("Rotate", 0.8, 9)],
-    [("Rotate", 1.0, 7), ("TranslateY", 0.8, 9)],
-    [("ShearX", 0.0, 0), ("Solarize", 0.8, 4)],
-    [("ShearY", 0.8, 0), ("Color", 0.6, 4)],
-    [("Color", 1.0, 0), ("Rotate", 0.6, 2)],
-    [("Equalize", 0.8, None), ("Equalize", 0.0, None)],
-    [("Equalize", 1.0, None), ("AutoContrast", 0.6, None)],
-    [("ShearY", 0.4, 7), ("SolarizeAdd", 0.6, 7)],
-    [("Posterize", 0.8, 2), ("Solarize", 0.6, 10)],
-    [("Solarize", 0.6, 8), ("Equalize", 0.6, 1)],
-    [("Color", 0.8, 6), ("Rotate", 0.4, 5)],
-]
+# AutoAugment policy "v0" (augmentation_schemes.py:12-39): 25 sub-policies of two (op, probability, magnitude) steps; "-" = the op
+# takes no magnitude.
+_POLICY_V0_TABLE = """
+    Equalize 0.8 -         | ShearY 0.8 4
+    Color 0.4 9            | Equalize 0.6 -
+    Color 0.4 1            | Rotate 0.6 8
+    Solarize 0.8 3         | Equalize 0.4 7
+    Solarize 0.4 2         | Solarize 0.6 2
+    Color 0.2 0            | Equalize 0.8 -
+    Equalize 0.4 -         | SolarizeAdd 0.8 3
+    ShearX 0.2 9           | Rotate 0.6 8
+    Color 0.6 1            | Equalize 1.0 -
+    Invert 0.4 -           | Rotate 0.6 0
+    Equalize 1.0 -         | ShearY 0.6 3
+    Color 0.4 7            | Equalize 0.6 -
+    Posterize 0.4 6        | AutoContrast 0.4 -
+    Solarize 0.6 8         | Color 0.6 9
+    Solarize 0.2 4         | Rotate 0.8 9
+    Rotate 1.0 7           | TranslateY 0.8 9
+    ShearX 0.0 0           | Solarize 0.8 4
+    ShearY 0.8 0           | Color 0.6 4
+    Color 1.0 0            | Rotate 0.6 2
+    Equalize 0.8 -         | Equalize 0.0 -
+    Equalize 1.0 -         | AutoContrast 0.6 -
+    ShearY 0.4 7           | SolarizeAdd 0.6 7
+    Posterize 0.8 2        | Solarize 0.6 10
+    Solarize 0.6 8         | Equalize 0.6 1
+    Color 0.8 6            | Rotate 0.4 5
+"""
+
+
+def _parse_policy(table):
+    def step(text):
+        name, prob, mag = text.split()
+        return (name, float(prob), None if mag == "-" else int(mag))
+    return [[step(part) for part in line.split("|")] for line in table.strip().splitlines()]
+
+
+_AUTO_AUGMENT_POLICY_V0 = _parse_policy(_POLICY_V0_TABLE)
 
 
 def _magnitude_to_enhance_kwargs(magnitude):
