@@ -580,6 +580,28 @@ class ViTEngine:
             a, b = self.hf[:self.B].float(), self.hfd[:self.B].float()
         return (a, b) if cfg.return_dist_token else (a + b) * 0.5
 
+    def capture_inference(self):
+        """Capture the inference forward (normalise + patchify -> logits, ~100 launches for ViT-B/16) into a HIP graph over the
+        engine's static buffers and return `run(images_u8) -> logits`.  At small batch the eager step is launch-bound (each launch
+        is a Python -> ctypes -> hipLaunchKernel round trip); the replay issues the whole chain with one call.  Training steps are
+        not captured: their dropout keys are kernel arguments that change every step."""
+        cfg = self.cfg
+        static_in = torch.zeros((self.B,) + cfg.image_size + (3,), dtype=torch.uint8, device=self.dev)
+        self.forward(static_in, training=False)          # warm-up outside the capture (lazy allocations, attribute setup)
+        torch.cuda.synchronize(self.dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward(static_in, training=False)
+
+        def run(images_u8):
+            if tuple(images_u8.shape) != tuple(static_in.shape) or images_u8.dtype != torch.uint8:
+                raise ValueError("expected uint8 images of shape %s" % (tuple(static_in.shape),))
+            static_in.copy_(images_u8)
+            graph.replay()
+            return out
+        run.graph = graph
+        return run
+
     def loss(self, labels):
         """Sparse softmax cross-entropy from logits, mean over the batch; also fills dlogits when training."""
         self.labels[:self.B].copy_(labels.to(torch.int32))

@@ -273,6 +273,22 @@ def test_distilled_variant_matches_oracle(pooling, include_top, return_dist):
         eng.train_step(torch.as_tensor(images, device="cuda"), torch.zeros(bsz, dtype=torch.long, device="cuda"))
 
 
+def test_inference_hip_graph_replay_matches_eager():
+    """ViTEngine.capture_inference(): the captured HIP graph reproduces the eager forward bit for bit on new inputs."""
+    cfg = _cfg()
+    eng, kw, images, _ = _setup(cfg, 4, training=False)
+    g = np.random.Generator(np.random.PCG64(9))
+    other = g.integers(0, 256, size=images.shape, dtype=np.uint8)
+    eager_a = eng.forward(torch.as_tensor(images, device="cuda"), training=False).clone()
+    eager_b = eng.forward(torch.as_tensor(other, device="cuda"), training=False).clone()
+    run = eng.capture_inference()
+    assert torch.equal(run(torch.as_tensor(images, device="cuda")), eager_a)
+    assert torch.equal(run(torch.as_tensor(other, device="cuda")), eager_b)
+    assert not torch.equal(eager_a, eager_b)
+    with pytest.raises(ValueError):
+        run(torch.zeros(1, 1, 1, 3, dtype=torch.uint8, device="cuda"))
+
+
 def test_vit_tiny_224_forward_config1():
     """BASELINE config 1: ViT-Ti/16 forward on 8x224x224x3 (the reference's CPU-runnable case)."""
     cfg = _cfg(patch_dim=192, n_heads=3, ff_dim=768, n_encoder_layers=12, image_size=(224, 224), classes=1000, dropout_rate=0.1)
