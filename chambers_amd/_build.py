@@ -22,6 +22,7 @@ SOURCES = {
     "layernorm.hip": [],
     "attention.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
+    "metric.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
           "-munsafe-fp-atomics"]

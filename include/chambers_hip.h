@@ -207,6 +207,18 @@ int chb_pool_tokens_bwd(const void* dout_bf16, const int32_t* argmax, void* dh_b
 int chb_tanh_fwd(float* z_inout, void* y_bf16, int64_t n, void* stream);
 int chb_tanh_bwd(const float* dy, const float* y, void* dz_bf16, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------- metric-learning head */
+/* L2Normalization(axis=-1) (layers/normalization.py:5-24; tf.nn.l2_normalize): y = x * rsqrt(max(sum x^2, 1e-12)),
+ * inv_norm fp32 [B] saved for backward; bwd: dx = inv * (dy - y <y, dy>). */
+int chb_l2_normalize_fwd(const float* x, float* y, float* inv_norm, int B, int D, void* stream);
+int chb_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int B, int D, void* stream);
+/* MultiSimilarityLoss + MultiSimilarityMiner (losses/metric_learning.py:124-178, miners.py:48-60) on embeddings fp32
+ * [B,D] and int32 labels [B]: loss_rows[i] as in compute_loss (the Keras loss value is their mean); when d_emb is not
+ * NULL also d(mean loss)/d(emb) fp32 [B,D], using workspace fp32 [B,B].  use_miner = 0 reproduces miner=None. */
+int chb_multi_similarity_loss(const float* emb, const int32_t* labels, float* loss_rows, float* workspace, float* d_emb,
+                              int B, int D, float pos_scale, float neg_scale, float threshold, float miner_margin,
+                              int use_miner, int ignore_diag, int ignore_negative_labels, void* stream);
+
 /* fp32 [R,C] -> bf16 [R,C] and/or bf16 [C,R] for a table of matrices (one launch). desc is a
  * device int64 array [n,4] = {src_offset, dst_offset, R, C} in elements; dst_t gets the
  * transposed copy at dst_offset (same element offsets). Either dst may be NULL. */
