@@ -284,6 +284,57 @@ __global__ void __launch_bounds__(256) affine_rgb_kernel(const uint8_t* __restri
     }
 }
 
+// The same transform over TW x (256/TW) output tiles for transforms that mix rows (rotation): one wave per tile, lane =
+// (row group r, column x) owns the pixels (x, r + RG*j), j = 0..3, RG = 64/TW.  One gather instruction then covers a TW x RG block
+// whose source footprint is a rotated TW x RG block (~11 rows of one or two lines for 27 degrees at TW = 16) instead of the 64
+// separate lines a row-long instruction touches under rotation; the tile is transposed through a wave-private 1 KiB LDS block so
+// that a lane stores 4 consecutive pixels (12 bytes).
+template <int TW>
+__global__ void __launch_bounds__(256) affine_rgb_tile_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
+                                                              int W, float a0, float a1, float a2, float b0, float b1, float b2, int fill) {
+    constexpr int TH = 256 / TW, RG = 64 / TW, QW = TW / 4;
+    __shared__ uint32_t tile[4][256];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
+    const int tiles = B * ty * tx;
+    const int64_t img_bytes = (int64_t)H * W * 3;
+    const uint32_t fillw = ((uint32_t)fill) * 0x01010101u;
+    const float fW = (float)W, fH = (float)H;
+    const int rg = lane / TW, xl = lane % TW;
+    const int orow = lane / QW, oq = lane % QW;     // store role: row of the tile, 4-pixel quad
+    uint32_t* lds = tile[wave];
+    for (int t = blockIdx.x * 4 + wave; t < tiles; t += gridDim.x * 4) {
+        const int n = t / (ty * tx), rem = t - n * (ty * tx);
+        const int y0 = (rem / tx) * TH, x0 = (rem - (rem / tx) * tx) * TW;
+        const uint8_t* img = in + (int64_t)n * img_bytes;
+        const bool last_img = n == B - 1;
+        const float fx = (float)(x0 + xl);
+        const float ax = a0 * fx, bx = b0 * fx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float fy = (float)(y0 + rg + RG * j);
+            const float ix = (ax + a1 * fy) + a2;            // (a0*x + a1*y) + a2, as the row kernel
+            const float iy = (bx + b1 * fy) + b2;
+            const float rx = roundf(ix), ry = roundf(iy);
+            const bool ok = (rx >= 0.0f) && (rx < fW) && (ry >= 0.0f) && (ry < fH);
+            const int off = ok ? ((int)ry * W + (int)rx) * 3 : 0;
+            const int over = (last_img && (int64_t)off + 4 > img_bytes) ? 1 : 0;
+            const uint32_t v = reinterpret_cast<const u32_unaligned*>(img + off - over)->v >> (8 * over);
+            lds[(rg + RG * j) * TW + xl] = ok ? v : fillw;
+        }
+        // wave-private block: every lane's writes land before the wave's reads (LDS operations of a wave complete in order)
+        const uint4 q = *reinterpret_cast<const uint4*>(lds + orow * TW + oq * 4);
+        const int oy = y0 + orow, ox = x0 + oq * 4;
+        if (oy < H && ox < W) {
+            px4_t o;
+            o.w[0] = (q.x & 0xffffffu) | (q.y << 24);
+            o.w[1] = ((q.y >> 8) & 0xffffu) | (q.z << 16);
+            o.w[2] = ((q.z >> 16) & 0xffu) | (q.w << 8);
+            *reinterpret_cast<px4_t*>(out + ((int64_t)n * H + oy) * W * 3 + (int64_t)ox * 3) = o;
+        }
+    }
+}
+
 // ---- cutout (tfa.image.random_cutout with explicit centres), :495-499 -------------
 // One wave per 4 consecutive image rows (4 independent 12-byte loads in flight per lane, no per-thread division).
 __global__ void __launch_bounds__(256) cutout_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
@@ -886,8 +937,23 @@ int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, 
     if (transform_host8) for (int i = 0; i < 8; ++i) t[i] = transform_host8[i];
     if (transform_host8 && t[6] == 0.0f && t[7] == 0.0f && C == 3 && (W & 3) == 0 && !((uintptr_t)out & 3) &&
         (int64_t)H * W * 3 < 2147483647LL) {
-        hipLaunchKernelGGL(affine_rgb_kernel, dim3(row_grid(((int64_t)B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
-                           t[0], t[1], t[2], t[3], t[4], t[5], fill & 0xff);
+        // rows stay rows (shear, translate): the row-per-wave kernel; rows mix (rotation): the tiled one.  CHB_AFFINE_ALGO forces
+        // 1 = rows, 2 = 32 x 8 tiles, 3 = 16 x 16 tiles (A/B timing).
+        const char* e = getenv("CHB_AFFINE_ALGO");
+        int algo = e ? atoi(e) : 0;
+        if (algo < 1 || algo > 3) algo = (t[3] == 0.0f) ? 1 : 3;
+        if (algo == 1) {
+            hipLaunchKernelGGL(affine_rgb_kernel, dim3(row_grid(((int64_t)B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
+                               t[0], t[1], t[2], t[3], t[4], t[5], fill & 0xff);
+        } else {
+            const int TW = algo == 2 ? 32 : 16, TH = 256 / TW;
+            const int64_t tiles = (int64_t)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+            int64_t blocks = (tiles + 3) / 4;
+            if (blocks > 32768) blocks = 32768;
+            auto kern = algo == 2 ? affine_rgb_tile_kernel<32> : affine_rgb_tile_kernel<16>;
+            hipLaunchKernelGGL(kern, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, t[0], t[1], t[2], t[3], t[4],
+                               t[5], fill & 0xff);
+        }
         CHB_LAUNCH_CHECK();
         return CHB_OK;
     }
