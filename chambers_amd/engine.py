@@ -301,10 +301,15 @@ def init_keras_weights(cfg, seed=1234):
 # data-parallel gradient exchange: device-agnostic so gloo/CPU tests cover it
 # ---------------------------------------------------------------------------------------------
 class GradBucketReducer:
-    """All-reduces contiguous slices of a flat gradient buffer as soon as backward marks them final.
+    """All-reduces contiguous slices of a flat gradient buffer once backward marks them final.
     One logical all-reduce (sum) per step, issued as len(buckets) asynchronous collectives so the
     exchange of block l overlaps the backward of blocks < l; `finish()` waits for all of them.
-    Averaging (x 1/world) is folded into the optimizer's grad_scale."""
+    Averaging (x 1/world) is folded into the optimizer's grad_scale.
+
+    `bucket_ready(k)` only queues the bucket; `flush()` issues what is queued.  The engine flushes right before a kernel with a
+    large grid of short workgroups (attention backward): the collective's workgroups then take their CUs from a launch the
+    hardware dispatcher load-balances, not from a persistent GEMM whose late workgroups would stretch that launch by the
+    collective's whole duration (measured with a stand-in collective, tools/rccl_contention.py)."""
 
     def __init__(self, flat_grad, buckets, process_group=None):
         import torch.distributed as dist
@@ -315,15 +320,24 @@ class GradBucketReducer:
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.world = dist.get_world_size(process_group) if self.active else 1
         self.handles = []
+        self.queued = []
 
     def bucket_ready(self, k):
-        if not self.active:
-            return
+        if self.active:
+            self.queued.append(k)
+
+    def flush(self):
+        for k in self.queued:
+            self._issue(k)
+        self.queued = []
+
+    def _issue(self, k):
         lo, hi = self.buckets[k]
         if hi > lo:
             self.handles.append(self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
+        self.flush()
         for h in self.handles:
             h.wait()
         self.handles = []
@@ -675,6 +689,7 @@ class ViTEngine:
             # attention branch (self.dz = dropout-backward of dx at site_proj(l))
             K.gemm_tn(a["o"], self.dz, self.g(pre + "proj/kernel"), m=Mp)
             K.gemm_nt(self.dz, self.wb(pre + "proj/kernel"), self.do, m=M)
+            self.reducer.flush()        # the previous block's bucket starts its exchange beside the attention backward
             K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], self.dqkv, self.B, n, cfg.n_heads, cfg.head_dim, rate,
                             key(rng.site_attn(l)))
             K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp)
@@ -697,6 +712,7 @@ class ViTEngine:
         K.gemm_tn(self.patches, self.dpatch, self.g("patch_embeddings/embedding/kernel"), m=self.Mpatch_p)
         K.colsum(self.dpatch, self.g("patch_embeddings/embedding/bias"), m=self.Mpatch)
         self.reducer.bucket_ready(L + 1)
+        self.reducer.flush()
 
     def _distilled_heads_backward(self, doutput):
         """d(loss)/d(outputs) of the distilled model: a pair (d_cls, d_dist) of fp32 [B, classes] (or [B, D] without a top), or

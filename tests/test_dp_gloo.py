@@ -31,8 +31,13 @@ def _worker(rank, world, port, out_dir):
     red = GradBucketReducer(flat, buckets)
     assert red.active and red.world == world and abs(red.grad_scale - 1.0 / world) < 1e-12
     # backward marks buckets final in order 0..L+1; collectives are asynchronous until finish()
+    # bucket_ready() queues, flush() issues (the engine flushes beside the attention backward and at the end of backward)
     for k in range(len(buckets)):
         red.bucket_ready(k)
+        if k % 2:
+            red.flush()
+            assert red.queued == [] and len(red.handles) == k + 1
+    red.flush()
     assert len(red.handles) == len(buckets)
     red.finish()
     assert red.handles == []

@@ -1,0 +1,90 @@
+"""Single-GPU rehearsal of what a collective running beside the backward pass costs the train step.
+
+An RCCL all-reduce is a kernel of a few dozen workgroups that holds its CUs for the length of the exchange.  This tool puts a
+stand-in (tools/cu_hog.hip: n_wg workgroups x 256 threads that spin for a given time, no memory traffic) on a side stream at
+every point where the engine hands a gradient bucket to the reducer, exactly as ProcessGroupNCCL orders its kernel behind the
+compute stream, and reports the step time with and without it.  Usage:
+    python tools/rccl_contention.py [batch] [n_wg] [micros]
+"""
+import ctypes, os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+n_wg = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+micros = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+
+so = os.path.join(ROOT, "build", "libcu_hog.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+if not os.path.exists(so):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "tools", "cu_hog.hip")])
+hog = ctypes.CDLL(so)
+hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+
+from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
+
+cfg = ViTConfig(patch_size=16, patch_dim=768, n_encoder_layers=12, n_heads=12, ff_dim=3072, dropout_rate=0.1, image_size=(224, 224), classes=1000)
+eng = ViTEngine(cfg, batch, training=True, seed=0)
+eng.load_keras_weights(init_keras_weights(cfg, seed=1234))
+g = np.random.Generator(np.random.PCG64(0))
+images = torch.as_tensor(g.integers(0, 256, size=(batch, 224, 224, 3), dtype=np.uint8), device="cuda")
+labels = torch.as_tensor(g.integers(0, 1000, size=(batch,)), device="cuda")
+side = torch.cuda.Stream()
+mode = {"on": False, "placement": "engine"}
+launched = [0]
+
+
+queued = []
+
+
+def bucket_ready(k):
+    if mode["on"]:
+        queued.append(k)
+        if mode["placement"] == "immediate":
+            flush()
+
+
+def flush():
+    for _ in queued:
+        ev = torch.cuda.Event()
+        ev.record()                   # the collective starts once the bucket's gradients are final ...
+        side.wait_event(ev)
+        hog.hog_launch(n_wg, micros, ctypes.c_void_p(side.cuda_stream))
+        launched[0] += 1
+    del queued[:]
+
+
+def finish():
+    flush()
+    if mode["on"]:
+        torch.cuda.current_stream().wait_stream(side)     # ... and the optimizer waits for all of them
+
+
+eng.reducer.bucket_ready = bucket_ready
+eng.reducer.flush = flush
+eng.reducer.finish = finish
+
+
+def run(steps):
+    for _ in range(3):
+        eng.train_step(images, labels, learning_rate=1e-3, weight_decay=0.05)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_step(images, labels, learning_rate=1e-3, weight_decay=0.05)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+base = run(10)
+mode["on"] = True
+print("batch %d  stand-in collective: %d WGs x %d us per gradient bucket   step alone %.2f ms   GEMM_ALGO=%s"
+      % (batch, n_wg, micros, base, os.environ.get("CHB_GEMM_ALGO", "default")))
+for placement in ("immediate", "engine"):      # immediate: at bucket_ready (behind a persistent GEMM); engine: where the engine flushes
+    mode["placement"] = placement
+    launched[0] = 0
+    t = run(10)
+    print("  placement %-9s %2.0f launches/step   step %.2f ms   (+%.2f ms, %.1f %%)" % (placement, launched[0] / 13, t, t - base, 100 * (t / base - 1)))
