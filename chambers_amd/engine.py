@@ -74,8 +74,9 @@ class ParamSpec:
 
 def build_param_table(cfg, decay_fn=None):
     """Internal parameter list in backward-completion order, with 1024-aligned offsets.
-    Returns (specs, total_elements, bucket_ranges) — bucket k is the slice whose gradients are
-    final after stage k of backward (stage 0 = heads + final norm, 1..L = blocks L-1..0, L+1 = embeddings)."""
+    Returns (specs, total_elements, bucket_ranges) — bucket k is the slice whose gradients are final after stage k of
+    backward: 0 = heads + final norm; for the s-th block from the top (s = 1..L) 2s-1 = its MLP, norm2 and projection
+    (final before its attention backward) and 2s = its QKV and norm1; 2L+1 = embeddings."""
     d, ff, n, kp = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens, cfg.patch_k
     specs, buckets = [], []
     off = 0
@@ -113,6 +114,8 @@ def build_param_table(cfg, decay_fn=None):
         add(p + "norm2/beta", (d,), False)
         add(p + "proj/kernel", (d, d), True)
         add(p + "proj/bias", (d,), False)
+        buckets.append((start, off))
+        start = off
         add(p + "qkv/kernel", (d, 3 * d), True)
         add(p + "qkv/bias", (3 * d,), False)
         add(p + "norm1/gamma", (d,), False)
@@ -302,7 +305,7 @@ def init_keras_weights(cfg, seed=1234):
 # ---------------------------------------------------------------------------------------------
 class GradBucketReducer:
     """All-reduces contiguous slices of a flat gradient buffer once backward marks them final.
-    One logical all-reduce (sum) per step, issued as len(buckets) asynchronous collectives so the
+    One logical all-reduce (sum) per step, issued as a handful of asynchronous collectives so the
     exchange of block l overlaps the backward of blocks < l; `finish()` waits for all of them.
     Averaging (x 1/world) is folded into the optimizer's grad_scale.
 
@@ -327,13 +330,18 @@ class GradBucketReducer:
             self.queued.append(k)
 
     def flush(self):
+        """One collective per run of adjacent queued buckets (they are contiguous slices of the flat buffer)."""
+        ranges = []
         for k in self.queued:
-            self._issue(k)
+            lo, hi = self.buckets[k]
+            if hi <= lo:
+                continue
+            if ranges and ranges[-1][1] == lo:
+                ranges[-1][1] = hi
+            else:
+                ranges.append([lo, hi])
         self.queued = []
-
-    def _issue(self, k):
-        lo, hi = self.buckets[k]
-        if hi > lo:
+        for lo, hi in ranges:
             self.handles.append(self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -689,7 +697,10 @@ class ViTEngine:
             # attention branch (self.dz = dropout-backward of dx at site_proj(l))
             K.gemm_tn(a["o"], self.dz, self.g(pre + "proj/kernel"), m=Mp)
             K.gemm_nt(self.dz, self.wb(pre + "proj/kernel"), self.do, m=M)
-            self.reducer.flush()        # the previous block's bucket starts its exchange beside the attention backward
+            # this block's MLP / projection gradients and the previous block's QKV gradients are final and adjacent in the flat
+            # buffer: one all-reduce, started beside the attention backward
+            self.reducer.bucket_ready(2 * (L - l) - 1)
+            self.reducer.flush()
             K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], self.dqkv, self.B, n, cfg.n_heads, cfg.head_dim, rate,
                             key(rng.site_attn(l)))
             K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp)
@@ -705,13 +716,13 @@ class ViTEngine:
             else:
                 K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
                                 self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d)
-            self.reducer.bucket_ready(L - l)
+            self.reducer.bucket_ready(2 * (L - l))
         # embedding stage
         K.embed_bwd(self.dx, self.dpatch, self.g("pos_embedding/embeddings"), self.g("add_cls_token/embeddings"), self.B, n, d, rate,
                     key(rng.SITE_EMBED), n_special=cfg.n_special)
         K.gemm_tn(self.patches, self.dpatch, self.g("patch_embeddings/embedding/kernel"), m=self.Mpatch_p)
         K.colsum(self.dpatch, self.g("patch_embeddings/embedding/bias"), m=self.Mpatch)
-        self.reducer.bucket_ready(L + 1)
+        self.reducer.bucket_ready(2 * L + 1)
         self.reducer.flush()
 
     def _distilled_heads_backward(self, doutput):

@@ -97,7 +97,7 @@ def test_model_builder_signature_names_and_errors():
     specs, _tot, buckets = build_param_table(ViTConfig(16, 768, 12, 12, 3072))
     real = sum(s.size for s in specs) - (1024 - 1000) * (768 + 1)
     assert real == 86567656
-    assert len(buckets) == 14 and buckets[0][0] == 0 and all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
+    assert len(buckets) == 2 + 2 * 12 and buckets[0][0] == 0 and all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
 
 
 def test_adamw_facade_regex_semantics():
@@ -199,7 +199,7 @@ def test_distilled_parameter_table_and_weight_roundtrip():
     for k in kw:
         np.testing.assert_array_equal(back[k], kw[k])
     specs, _, buckets = build_param_table(cfg)
-    assert set(keras_variable_names(cfg)) == {s.name for s in specs} and len(buckets) == 2 + 2
+    assert set(keras_variable_names(cfg)) == {s.name for s in specs} and len(buckets) == 2 + 2 * cfg.n_encoder_layers
     assert keras_variable_names(cfg)["add_cls_token/embeddings"] == ["add_cls_token/embeddings:0", "add_dist_token/embeddings:0"]
     with pytest.raises(ValueError):
         ViTConfig(16, 128, 2, 2, 256, distilled=True, feature_dim=64)

@@ -40,15 +40,8 @@ launched = [0]
 queued = []
 
 
-def bucket_ready(k):
-    if mode["on"]:
-        queued.append(k)
-        if mode["placement"] == "immediate":
-            flush()
-
-
-def flush():
-    for _ in queued:
+def launch():
+    if queued:                        # adjacent buckets go out as ONE collective (GradBucketReducer.flush)
         ev = torch.cuda.Event()
         ev.record()                   # the collective starts once the bucket's gradients are final ...
         side.wait_event(ev)
@@ -57,8 +50,20 @@ def flush():
     del queued[:]
 
 
+def bucket_ready(k):
+    if mode["on"]:
+        queued.append(k)
+        if mode["placement"] == "immediate" and k % 2 == 0:     # a block's (or the head's) gradients are complete
+            launch()
+
+
+def flush():                          # the engine's flush points: before each attention backward, end of backward
+    if mode["placement"] == "engine":
+        launch()
+
+
 def finish():
-    flush()
+    launch()
     if mode["on"]:
         torch.cuda.current_stream().wait_stream(side)     # ... and the optimizer waits for all of them
 
