@@ -54,6 +54,7 @@ PROTOTYPES = {
     "chb_l2_normalize_bwd": [P, P, P, P, c_int, c_int, P],
     "chb_multi_similarity_loss": [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_int, P],
     "chb_resize": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "chb_resize_ragged": [P, c_int64, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
     "chb_crop_flip": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P],
     "chb_rescale": [P, c_int, P, c_int64, c_float, c_float, P],
     "chb_pool_tokens_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],

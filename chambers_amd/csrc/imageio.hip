@@ -112,6 +112,84 @@ __global__ void __launch_bounds__(256) resize_nearest_kernel(const T* __restrict
     }
 }
 
+// Ragged batch (the decode -> Resizing step of data/dataset.py + augmentations/__init__.py:11): B decoded RGB
+// images of different sizes, packed back to back in one uint8 buffer (`offs[b]` = byte offset of image b, `hw[2b], hw[2b+1]` = its
+// height and width), are resized to one [B, OH, OW, 3] batch in a single launch -- per-image scales H/OH, W/OW, otherwise the
+// arithmetic of the kernels above.  One thread = 4 consecutive output pixels of a row.  OUT: fp32 (tf.image.resize) or uint8
+// (tf.cast(float -> uint8) of it: truncation), the layout the augmentation kernels take.
+template <bool BILINEAR, typename TOUT>
+__global__ void __launch_bounds__(256) resize_ragged_rgb8_kernel(const uint8_t* __restrict__ in, const int64_t* __restrict__ offs,
+                                                                 const int32_t* __restrict__ hw, TOUT* __restrict__ out, int B, int OH,
+                                                                 int OW, int64_t total_bytes) {
+    const int wq = OW >> 2;
+    const int64_t total = (int64_t)B * OH * wq;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(idx % wq);
+        const int64_t r = idx / wq;
+        const int oy = (int)(r % OH), b = (int)(r / OH);
+        const int H = hw[2 * b], W = hw[2 * b + 1];
+        const int64_t base = offs[b];
+        const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+        float f[12];
+        if (BILINEAR) {
+            const float fy = ((float)oy + 0.5f) * sy - 0.5f;
+            const float fy0 = floorf(fy);
+            const int y0 = max((int)fy0, 0), y1 = min((int)ceilf(fy), H - 1);
+            const float ty = fy - fy0;
+            const int64_t row0 = base + (int64_t)y0 * W * 3, row1 = base + (int64_t)y1 * W * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ox = 4 * xq + i;
+                const float fx = ((float)ox + 0.5f) * sx - 0.5f;
+                const float fx0 = floorf(fx);
+                const int x0 = max((int)fx0, 0), x1 = min((int)ceilf(fx), W - 1);
+                const float tx = fx - fx0;
+                uint32_t px[4];
+                const int64_t o4[4] = {row0 + (int64_t)x0 * 3, row0 + (int64_t)x1 * 3, row1 + (int64_t)x0 * 3, row1 + (int64_t)x1 * 3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int over = (o4[k] + 4 > total_bytes) ? 1 : 0;     // last pixel of the buffer: step back one byte and shift
+                    px[k] = reinterpret_cast<const u32_unaligned*>(in + o4[k] - over)->v >> (8 * over);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float tl = (float)((px[0] >> (8 * c)) & 0xffu), tr = (float)((px[1] >> (8 * c)) & 0xffu);
+                    const float bl = (float)((px[2] >> (8 * c)) & 0xffu), br = (float)((px[3] >> (8 * c)) & 0xffu);
+                    const float top = tl + (tr - tl) * tx;
+                    const float bot = bl + (br - bl) * tx;
+                    f[3 * i + c] = top + (bot - top) * ty;
+                }
+            }
+        } else {
+            const int iy = min((int)floorf(((float)oy + 0.5f) * sy), H - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ix = min((int)floorf(((float)(4 * xq + i) + 0.5f) * sx), W - 1);
+                const int64_t o1 = base + ((int64_t)iy * W + ix) * 3;
+                const int over = (o1 + 4 > total_bytes) ? 1 : 0;
+                const uint32_t px = reinterpret_cast<const u32_unaligned*>(in + o1 - over)->v >> (8 * over);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) f[3 * i + c] = (float)((px >> (8 * c)) & 0xffu);
+            }
+        }
+        const int64_t o0 = (((int64_t)b * OH + oy) * OW + 4 * xq) * 3;
+        if (sizeof(TOUT) == 4) {
+            float4* o = reinterpret_cast<float4*>(out + o0);
+            o[0] = make_float4(f[0], f[1], f[2], f[3]);
+            o[1] = make_float4(f[4], f[5], f[6], f[7]);
+            o[2] = make_float4(f[8], f[9], f[10], f[11]);
+        } else {
+            uint32_t w[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                w[k] = ((uint32_t)(int)f[4 * k] & 0xffu) | (((uint32_t)(int)f[4 * k + 1] & 0xffu) << 8) |
+                       (((uint32_t)(int)f[4 * k + 2] & 0xffu) << 16) | (((uint32_t)(int)f[4 * k + 3] & 0xffu) << 24);
+            uint32_t* o = reinterpret_cast<uint32_t*>(out + o0);
+            o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+        }
+    }
+}
+
 // crop + flips as a gather of whole pixels of `psz` bytes.  One wave per output row (no per-thread division); uint8 RGB rows
 // move 4 pixels (12 bytes) per lane with one unaligned dword load per source pixel, everything else byte-wise.
 __global__ void __launch_bounds__(256) crop_flip_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H, int W,
@@ -216,6 +294,28 @@ int chb_resize(const void* in, int in_dtype, void* out, int B, int H, int W, int
     } else {
         if (in_dtype == CHB_DT_U8) hipLaunchKernelGGL(resize_nearest_kernel<uint8_t>, grid, block, 0, s, (const uint8_t*)in, (uint8_t*)out, B, H, W, C, OH, OW, sy, sx);
         else hipLaunchKernelGGL(resize_nearest_kernel<float>, grid, block, 0, s, (const float*)in, (float*)out, B, H, W, C, OH, OW, sy, sx);
+    }
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_resize_ragged(const void* packed_u8, int64_t packed_bytes, const int64_t* offsets_dev, const int32_t* hw_dev, int B, void* out,
+                      int out_dtype, int OH, int OW, int method, void* stream) {
+    if (B < 0 || OH <= 0 || OW <= 0 || packed_bytes < 0) return CHB_EINVAL;
+    if (out_dtype != CHB_DT_U8 && out_dtype != CHB_DT_F32) return CHB_EINVAL;
+    if (method != CHB_RESIZE_BILINEAR && method != CHB_RESIZE_NEAREST) return CHB_EUNSUPPORTED;
+    if (OW & 3) return CHB_EUNSUPPORTED;          // a lane writes 4 pixels (12 bytes / 48 bytes, aligned)
+    if (B == 0) return CHB_OK;
+    if (!packed_u8 || !offsets_dev || !hw_dev || !out || packed_bytes < 4 || ((uintptr_t)out & 15)) return CHB_EINVAL;
+    const dim3 grid(grid_1d((int64_t)B * OH * (OW / 4))), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t* in = (const uint8_t*)packed_u8;
+    if (method == CHB_RESIZE_BILINEAR) {
+        if (out_dtype == CHB_DT_F32) hipLaunchKernelGGL((resize_ragged_rgb8_kernel<true, float>), grid, block, 0, s, in, offsets_dev, hw_dev, (float*)out, B, OH, OW, packed_bytes);
+        else hipLaunchKernelGGL((resize_ragged_rgb8_kernel<true, uint8_t>), grid, block, 0, s, in, offsets_dev, hw_dev, (uint8_t*)out, B, OH, OW, packed_bytes);
+    } else {
+        if (out_dtype == CHB_DT_F32) hipLaunchKernelGGL((resize_ragged_rgb8_kernel<false, float>), grid, block, 0, s, in, offsets_dev, hw_dev, (float*)out, B, OH, OW, packed_bytes);
+        else hipLaunchKernelGGL((resize_ragged_rgb8_kernel<false, uint8_t>), grid, block, 0, s, in, offsets_dev, hw_dev, (uint8_t*)out, B, OH, OW, packed_bytes);
     }
     CHB_LAUNCH_CHECK();
     return CHB_OK;

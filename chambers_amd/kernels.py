@@ -162,6 +162,26 @@ def resize(x, out_h, out_w, method="bilinear"):
     return out
 
 
+def resize_ragged(packed, offsets, hw, out_h, out_w, method="bilinear", out_dtype=torch.float32, out=None):
+    """B RGB uint8 images of different sizes, packed back to back (`packed` uint8 [bytes] on the GPU, `offsets` int64 [B],
+    `hw` int32 [B,2]) -> one [B,out_h,out_w,3] batch in a single launch; fp32 (tf.image.resize) or uint8 (its truncating cast)."""
+    _lib.require_gpu(packed, offsets, hw)
+    if method not in ("bilinear", "nearest"):
+        raise ValueError("unsupported interpolation %r (bilinear, nearest)" % (method,))
+    if packed.dtype != torch.uint8 or offsets.dtype != torch.int64 or hw.dtype != torch.int32:
+        raise ValueError("packed uint8, offsets int64, hw int32 expected")
+    if out_dtype not in (torch.float32, torch.uint8):
+        raise ValueError("out_dtype must be float32 or uint8")
+    b = int(offsets.numel())
+    if tuple(hw.shape) != (b, 2):
+        raise ValueError("hw must be [B, 2] (height, width)")
+    if out is None:
+        out = torch.empty((b, int(out_h), int(out_w), 3), dtype=out_dtype, device=packed.device)
+    _lib.call("chb_resize_ragged", _lib.ptr(packed), int(packed.numel()), _lib.ptr(offsets), _lib.ptr(hw), b, _lib.ptr(out),
+              0 if out.dtype == torch.uint8 else 1, int(out_h), int(out_w), 0 if method == "bilinear" else 1, _s())
+    return out
+
+
 def crop_flip(x, out_h, out_w, offsets=None, flips=None):
     """Window gather with optional per-image flips.  offsets: (y, x) tuple for the whole batch, or an int32 [B,2] array /
     tensor; flips: uint8 [B] (bit 0 left-right, bit 1 up-down) or None."""

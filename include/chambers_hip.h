@@ -154,6 +154,12 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
  * image_augmentations.py:686-748): NHWC in (uint8 or fp32) -> [B,OH,OW,C]; bilinear writes fp32, nearest the input
  * dtype; half-pixel centres, no antialias (TF2). */
 int chb_resize(const void* in, int in_dtype, void* out, int B, int H, int W, int C, int OH, int OW, int method, void* stream);
+/* The decode -> Resizing step in front of batching (data/dataset.py:264-315 maps read_and_decode_image, the training scripts map
+ * Resizing per element, test_units/data/test_dataset.py:176): B decoded RGB uint8 images of DIFFERENT sizes packed back to back in
+ * one device buffer (offsets_dev[b] = byte offset, hw_dev[2b], hw_dev[2b+1] = height, width) -> one [B,OH,OW,3] batch in a single
+ * launch.  Same arithmetic as chb_resize per image; out fp32 (tf.image.resize) or uint8 (its tf.cast: truncation).  OW % 4 == 0. */
+int chb_resize_ragged(const void* packed_u8, int64_t packed_bytes, const int64_t* offsets_dev, const int32_t* hw_dev, int B, void* out,
+                      int out_dtype, int OH, int OW, int method, void* stream);
 /* CenterCrop / RandomCrop / RandomFlip (augmentations/__init__.py:1-13) as one gather of whole pixels of
  * `pixel_bytes` bytes: window offset (y, x) = offsets_dev[b] (per_image) / offsets_dev[0] / (oy0, ox0) when NULL;
  * flips_dev[b] bit 0 = left-right, bit 1 = up-down inside the window (NULL = none). */
