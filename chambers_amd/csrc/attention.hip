@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const bf16_t* __restri
     constexpr int NKP = 32 * NTP, NT = 2 * NTP;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[NKP * HD];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[NKP * HD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int Dm = H * HD;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------ backward
 // LDS: K, V, Q, dO images [NP][64] (row-read swizzle; transposed reads take a 2-way conflict),
 // dS double buffer [2][32][NP + 8], lse*log2e and delta per query.
-template <int NTP, bool DROP, int NW>   // NW waves per workgroup: 8, or 16 (4 per SIMD, <= 128 registers) for 129..224 tokens
+template <int NTP, bool DROP, int NW, bool DBIAS = true>   // NW waves per workgroup: 8, or 16 (4 per SIMD, <= 128 registers) for 129..224 tokens
 __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, float scale,
                                                        float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key,
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
     float* lse2 = reinterpret_cast<float*>(dSs + 2 * 32 * DSLD);
     float* delta = lse2 + NP;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int Dm = H * HD;
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
                 w.x = pack_bf16x2(dq[0], dq[1]);
                 w.y = pack_bf16x2(dq[2], dq[3]);
                 *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * dtw + 4 * g) = w;
-                dqsum += dq;
+                if (DBIAS) dqsum += dq;
             }
         }
         __syncthreads();   // dS of block `it` is published; dS buffer (it - 1) & 1 is free for block it + 1
@@ -373,16 +373,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
             }
         }
     }
-    if (dbias) {
-        // bias gradients of the fused QKV projection = column sums of dqkv over this head's rows: reduce over the 16 lanes
-        // that hold different queries / keys, then one atomic per (wave, column)
-        const int dtw = wave & 3;
+    if (DBIAS && dbias) {
+        // bias gradients of the fused QKV projection = column sums of dqkv over this head's rows.  Every wave folds its tiles over
+        // the 16 lanes that hold different queries / keys and leaves 192 column partials in LDS (the operand images are dead after the
+        // loop's last barrier); 192 threads add the waves' partials and write the head's sums ONCE: to this batch element's row of
+        // the workspace (dbias_rows: plain stores, reduced over the batch by dbias_reduce_kernel) or with one atomic per column.
+        float* red = reinterpret_cast<float*>(smem_raw);       // [NW][192]: q | k | v columns of this head (over the dead K image)
+        if (wave < 8) {                                        // dQ tiles belong to waves 0..7: d-tile wave & 3, query sub-tile wave >> 2
+            const int dtw = wave & 3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (wave >= 8) break;   // dQ tiles belong to waves 0..7
-            float v = dqsum[r];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (i == 0) atomicAdd(dbias + h * HD + 16 * dtw + 4 * g + r, v);
+            for (int r = 0; r < 4; ++r) {
+                float v = dqsum[r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (i == 0) red[wave * 192 + 16 * dtw + 4 * g + r] = v;
+            }
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -400,10 +404,23 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
                 vk += __shfl_xor(vk, 1, 64); vk += __shfl_xor(vk, 2, 64); vk += __shfl_xor(vk, 4, 64); vk += __shfl_xor(vk, 8, 64);
                 vv += __shfl_xor(vv, 1, 64); vv += __shfl_xor(vv, 2, 64); vv += __shfl_xor(vv, 4, 64); vv += __shfl_xor(vv, 8, 64);
                 if (i == 0) {
-                    atomicAdd(dbias + Dm + h * HD + 16 * dt + 4 * g + r, vk);
-                    atomicAdd(dbias + 2 * Dm + h * HD + 16 * dt + 4 * g + r, vv);
+                    red[wave * 192 + 64 + 16 * dt + 4 * g + r] = vk;
+                    red[wave * 192 + 128 + 16 * dt + 4 * g + r] = vv;
                 }
             }
+        __syncthreads();
+        if (wave < 3) {                                        // 192 threads: part = wave, column = lane
+            const int part = wave, col = lane;
+            float sum = 0.f;
+            if (part == 0) {
+                const int dtw = col >> 4;                      // the two waves that own this d-tile (query sub-tiles 0 and 1)
+                sum = red[dtw * 192 + col] + red[(dtw + 4) * 192 + col];
+            } else {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += red[w * 192 + part * 64 + col];
+            }
+            dbias[(int64_t)b * 3 * Dm + part * Dm + h * HD + col] = sum;
+        }
     }
 }
 
@@ -451,7 +468,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_stream_kernel(const bf16_t* _
     __shared__ __attribute__((aligned(16))) bf16_t Kb[2][KC * HD];
     __shared__ __attribute__((aligned(16))) bf16_t Vb[2][KC * HD];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int Dm = H * HD;
@@ -585,7 +602,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __re
     __shared__ __attribute__((aligned(16))) bf16_t Gb[2][32 * HD];
     __shared__ float l2b[2][32], dlb[2][32];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int Dm = H * HD;
@@ -739,7 +756,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(const bf16_t* __res
     __shared__ __attribute__((aligned(16))) bf16_t Kb[2][KC * HD];
     __shared__ __attribute__((aligned(16))) bf16_t Vb[2][KC * HD];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int Dm = H * HD;
@@ -869,6 +886,15 @@ constexpr size_t bwd_lds_bytes() {
     return (size_t)(4 * 32 * NTP * HD + 2 * 32 * (32 * NTP + 8)) * sizeof(bf16_t) + (size_t)2 * 32 * NTP * sizeof(float);
 }
 
+// dbias[c] += sum over the B rows of ws[b][c]: (C / 256) x 16 workgroups, each column finishes with 16 atomics
+__global__ void __launch_bounds__(256) dbias_reduce_kernel(const float* __restrict__ ws, int B, int C, float* __restrict__ dbias) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float sum = 0.f;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) sum += ws[(int64_t)b * C + c];
+    atomicAdd(dbias + c, sum);
+}
+
 }  // namespace
 
 extern "C" {
@@ -913,7 +939,7 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
 }
 
 int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N, int H, int hd,
-                      float drop_rate, uint32_t drop_key, float* dbias_qkv, void* stream) {
+                      float drop_rate, uint32_t drop_key, float* dbias_qkv, float* dbias_ws, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
     if (hd != HD) return CHB_EUNSUPPORTED;
     if ((double)B * H * N * N >= 4294967296.0) return CHB_EUNSUPPORTED;
@@ -944,23 +970,35 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
         CHB_LAUNCH_CHECK();
         return CHB_OK;
     }
-#define CHB_BWD(NTP, NW)                                                                                                             \
+    if (dbias_qkv && !dbias_ws) return CHB_EINVAL;      // the one-pass kernel writes per-batch-element rows, folded below
+    float* db = dbias_qkv ? dbias_ws : nullptr;
+    const int db_rows = dbias_qkv ? 1 : 0;
+#define CHB_BWD_V(NTP, NW, DB)                                                                                                    \
     do {                                                                                                                         \
         const size_t lds = bwd_lds_bytes<NTP>();                                                                                 \
-        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
-            hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, true, NW, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
+            hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, false, NW, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
             return CHB_ELAUNCH;                                                                                                  \
-        if (thr) hipLaunchKernelGGL((attn_bwd_kernel<NTP, true, NW>), grid, dim3(NW * 64), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
-                           lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);                           \
-        else hipLaunchKernelGGL((attn_bwd_kernel<NTP, false, NW>), grid, dim3(NW * 64), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
-                           lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);                           \
+        if (thr) hipLaunchKernelGGL((attn_bwd_kernel<NTP, true, NW, DB>), grid, dim3(NW * 64), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
+                           lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, db);                                  \
+        else hipLaunchKernelGGL((attn_bwd_kernel<NTP, false, NW, DB>), grid, dim3(NW * 64), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
+                           lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, db);                                  \
+    } while (0)
+    // the bias-gradient epilogue is its own instantiation: its four extra accumulators and the cross-wave fold cost the 16-wave
+    // kernel (128 registers) 64-88 bytes of scratch per lane, without it the kernel does not spill
+#define CHB_BWD(NTP, NW)                  \
+    do {                                  \
+        if (db) CHB_BWD_V(NTP, NW, true); \
+        else CHB_BWD_V(NTP, NW, false);   \
     } while (0)
     if (N <= 32) CHB_BWD(1, 8);
     else if (N <= 64) CHB_BWD(2, 8);
     else if (N <= 128) CHB_BWD(4, 8);
     else if (algo_env && atoi(algo_env) == 1) CHB_BWD(7, 8);   // 8-wave variant kept for A/B timing
     else CHB_BWD(7, 16);
+#undef CHB_BWD_V
 #undef CHB_BWD
+    if (db_rows) hipLaunchKernelGGL(dbias_reduce_kernel, dim3((3 * H * HD + 255) / 256, 16), dim3(256), 0, s, dbias_ws, B, 3 * H * HD, dbias_qkv);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

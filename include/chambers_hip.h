@@ -141,9 +141,12 @@ int chb_layernorm_bwd(const void* dy_bf16, const float* x, int64_t x_stride, con
  * 384x384) through the streaming forward and the two-pass backward. */
 int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate,
                       uint32_t drop_key, void* stream);
-/* dbias_qkv (fp32 [3*H*hd], optional): += column sums of dqkv (bias gradient of the fused QKV projection). */
+/* dbias_qkv (fp32 [3*H*hd], optional): += column sums of dqkv (bias gradient of the fused QKV projection), taken from the
+ * fp32 accumulators.  dbias_ws: fp32 [B, 3*H*hd] scratch, required with dbias_qkv when N <= 224 (every head writes its sums to
+ * its batch element's row with plain stores and a small second launch folds the rows into dbias_qkv); longer sequences (two-pass
+ * kernels) add with one atomic per workgroup and column and ignore it. */
 int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N,
-                      int H, int hd, float drop_rate, uint32_t drop_key, float* dbias_qkv, void* stream);
+                      int H, int hd, float drop_rate, uint32_t drop_key, float* dbias_qkv, float* dbias_ws, void* stream);
 
 /* ---------------------------------------------------------------- input side */
 #define CHB_DT_U8 0

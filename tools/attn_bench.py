@@ -37,4 +37,10 @@ for rate in (0.0, 0.1):
         os.environ["CHB_ATTN_BWD_ALGO"] = algo
         b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7))
         line += "   bwd[%s] %.3f ms (%.0f TF/s)" % (label, b, 2.5 * fl / b / 1e9)
+    os.environ["CHB_ATTN_BWD_ALGO"] = "0"
+    dbias = torch.zeros(3 * D, device="cuda")
+    ws = torch.empty(B * 3 * D, device="cuda")
+    b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7, dbias=dbias, dbias_ws=ws))
+    c = t(lambda: K.colsum(dqkv, dbias, m=B * N))
+    line += "   bwd[default + fused qkv bias gradient] %.3f ms   (stand-alone column sums of dqkv: %.3f ms)" % (b, c)
     print(line, flush=True)
