@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) affine_kernel(const uint8_t* __restrict__
                                                      int W, int C, const float* __restrict__ tdev, int per_image,
                                                      float t0, float t1, float t2, float t3, float t4, float t5,
                                                      float t6, float t7, int fill) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = (W + 3) >> 2;  // x-quads per row
     const int rows = B * H;
     const int64_t total_bytes = (int64_t)B * H * W * C;
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) affine_rgb_tile_kernel(const uint8_t* __r
 __global__ void __launch_bounds__(256) cutout_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
                                                      int W, int C, const int32_t* __restrict__ centers, int half,
                                                      int value) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = (W + 3) >> 2;
     const int rows = B * H;
     for (int row0 = (blockIdx.x * 4 + wave) * 4; row0 < rows; row0 += gridDim.x * 16) {
@@ -596,7 +596,7 @@ __device__ __forceinline__ uint8_t sharp_finish(uint8_t deg, uint8_t orig, float
 template <int MODE>
 __global__ void __launch_bounds__(256) sharpness_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
                                                         int W, int C, float factor) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = (W + 3) >> 2;
     const int rows = B * H;
     const int64_t total_bytes = (int64_t)B * H * W * C;
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(256) sharpness_kernel(const uint8_t* __restric
 template <int MODE>
 __global__ void __launch_bounds__(256) sharpness_rows_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
                                                              int W, float factor) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = W >> 2;
     const int hp = (H + 1) >> 1;                 // row pairs per image
     const int pairs = B * hp;

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) dropout_bwd_kernel(const float* __restric
 // grid = (col blocks of 256 columns, row slabs of 512 rows); lane owns 4 columns.
 __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ x, int64_t ld, float* __restrict__ out, int M, int N) {
     __shared__ float red[4][256];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = blockIdx.x * 256 + lane * 4;
     const int r0 = blockIdx.y * 512;
     int r1 = r0 + 512;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
 __global__ void __launch_bounds__(256) softmax_ce_kernel(const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
                                                          float* __restrict__ loss, bf16_t* __restrict__ dl, int64_t ld_d, int B,
                                                          int classes, float grad_scale) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
         const float* z = logits + (int64_t)b * ld;
         float mx = -INFINITY;

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) resize_ragged_rgb8_kernel(const uint8_t* 
 __global__ void __launch_bounds__(256) crop_flip_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H, int W,
                                                         int psz, int OH, int OW, const int32_t* __restrict__ offsets, int per_image,
                                                         int oy0, int ox0, const uint8_t* __restrict__ flips) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int rows = B * OH;
     const int64_t total_bytes = (int64_t)B * H * W * psz;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D,
                                                      float eps) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nchunk = D >> 2;
     const float inv_d = 1.0f / (float)D;
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      int D, bf16_t* __restrict__ dz, float* __restrict__ dzsum, float drop_scale,
                                                      uint32_t drop_thr, uint32_t drop_key) {
     __shared__ float red[3][4][NCH * 256];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nchunk = D >> 2;
     const float inv_d = 1.0f / (float)D;
     float4 gam[NCH], dg[NCH], db[NCH];

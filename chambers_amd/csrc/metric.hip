@@ -13,7 +13,7 @@
 namespace {
 
 __device__ __forceinline__ float block_reduce(float v, float* red, int op) {   // op 0 sum, 1 max, 2 min; 256 threads
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float t = __shfl_xor(v, o, 64);
