@@ -47,22 +47,33 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict_
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(idx / dq), d = (int)(idx - (int64_t)t * dq) * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int b = b0; b < b1; ++b) {
-            const int64_t e = ((int64_t)b * N + t) * D + d;
-            float4 v = *reinterpret_cast<const float4*>(dx + e);
-            if (thr) {
-                bool k0, k1, k2, k3;
-                chb_keep2((uint32_t)(e >> 1), key, thr, k0, k1);
-                chb_keep2((uint32_t)(e >> 1) + 1u, key, thr, k2, k3);
-                v.x = k0 ? v.x * scale : 0.f; v.y = k1 ? v.y * scale : 0.f;
-                v.z = k2 ? v.z * scale : 0.f; v.w = k3 ? v.w * scale : 0.f;
+        for (int bb = b0; bb < b1; bb += 4) {     // four batch elements per trip: their loads are in flight together
+            float4 v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = min(bb + u, b1 - 1);
+                v4[u] = *reinterpret_cast<const float4*>(dx + ((int64_t)b * N + t) * D + d);
             }
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            if (t >= ns) {
-                uint2 o;
-                o.x = pack_bf16x2(v.x, v.y);
-                o.y = pack_bf16x2(v.z, v.w);
-                *reinterpret_cast<uint2*>(dpatch + ((int64_t)b * (N - ns) + (t - ns)) * D + d) = o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = bb + u;
+                if (b >= b1) break;
+                const int64_t e = ((int64_t)b * N + t) * D + d;
+                float4 v = v4[u];
+                if (thr) {
+                    bool k0, k1, k2, k3;
+                    chb_keep2((uint32_t)(e >> 1), key, thr, k0, k1);
+                    chb_keep2((uint32_t)(e >> 1) + 1u, key, thr, k2, k3);
+                    v.x = k0 ? v.x * scale : 0.f; v.y = k1 ? v.y * scale : 0.f;
+                    v.z = k2 ? v.z * scale : 0.f; v.w = k3 ? v.w * scale : 0.f;
+                }
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                if (t >= ns) {
+                    uint2 o;
+                    o.x = pack_bf16x2(v.x, v.y);
+                    o.y = pack_bf16x2(v.z, v.w);
+                    *reinterpret_cast<uint2*>(dpatch + ((int64_t)b * (N - ns) + (t - ns)) * D + d) = o;
+                }
             }
         }
         float* pp = dpos + (int64_t)t * D + d;
