@@ -924,6 +924,8 @@ struct Tn256Params {
     float* W; int64_t ldw;
     int M, Kd, Nd;
     int tiles_k, tiles_n, splits, steps_per_split;
+    float* ws;        // optional [splits][Kd][Nd] fp32: every work item stores its partial tile there (plain 16-byte stores) and
+                      // tn_reduce_kernel folds the planes into W; without it the partials meet in fp32 atomics on W
 };
 
 __device__ __forceinline__ void stage_half_tn(const bf16_t* __restrict__ g, int64_t ld, int m0, int col0, int ncols, bf16_t* lds_half,
@@ -1089,6 +1091,25 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
     // acc[a][b][r]: kd = k0 + wk*128 + a*16 + i, nd = n0 + wn*64 + b*16 + 4g + r.  Stage one 16(kd) x 64(nd) tile row
     // at a time and add it as 16 full 256-byte rows.
     float* stage = reinterpret_cast<float*>(smem + 2 * 4 * 8192) + wave * 1024;
+    if (p.ws) {
+        // partial plane of this split: lane = (row r4 + 4k of the tile row, 4 columns) -> 4 rows x 256 bytes per store instruction
+        float* plane = p.ws + (int64_t)split * p.Kd * p.Nd;
+        const int r4 = lane >> 4, c4 = lane & 15;
+        const int nd4 = n0 + wn * 64 + 4 * c4;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) *reinterpret_cast<float4_t*>(stage + i * 64 + (((4 * b + g) ^ i) << 2)) = acc[a][b];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * k + r4;
+                const float4_t v = *reinterpret_cast<const float4_t*>(stage + r * 64 + ((c4 ^ r) << 2));
+                const int kd = k0 + wk * 128 + a * 16 + r;
+                if (kd < p.Kd && nd4 < p.Nd) *reinterpret_cast<float4_t*>(plane + (int64_t)kd * p.Nd + nd4) = v;
+            }
+        }
+        return;
+    }
     const int nd = n0 + wn * 64 + lane;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
@@ -1100,6 +1121,26 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
             const int kd = k0 + wk * 128 + a * 16 + r;
             if (kd < p.Kd && nd < p.Nd) atomicAdd(p.W + (int64_t)kd * p.ldw + nd, v);
         }
+    }
+}
+
+// W[kd][nd] += sum over the splits of ws[s][kd][nd]  (one thread = 4 columns; Nd % 4 == 0)
+__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ ws, int splits, int Kd, int Nd, float* __restrict__ W,
+                                                        int64_t ldw) {
+    const int nq = Nd >> 2;
+    const int64_t total = (int64_t)Kd * nq, plane = (int64_t)Kd * Nd;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int kd = (int)(idx / nq), c = (int)(idx - (int64_t)kd * nq) * 4;
+        const float* src = ws + (int64_t)kd * Nd + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(src + sp * plane);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(W + (int64_t)kd * ldw + c);
+        float4 w = *dst;
+        w.x += acc.x; w.y += acc.y; w.z += acc.z; w.w += acc.w;
+        *dst = w;
     }
 }
 
@@ -1211,27 +1252,65 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
 
 int chb_gemm_tn(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int M, int Kd, int Nd,
                 void* stream) {
+    return chb_gemm_tn_ws(X, ldx, dY, ldy, dW, ldw, M, Kd, Nd, nullptr, 0, 1, stream);
+}
+
+// split plan of the persistent 256x256 weight-gradient kernel; `planes`: partial planes in caller scratch instead of atomics
+struct Tn256Plan { bool use256; int tiles_k, tiles_n, splits, steps_per_split; bool planes; };
+
+static Tn256Plan tn256_plan(int M, int Kd, int Nd, const float* workspace, int64_t workspace_bytes, const float* dW, int64_t ldw) {
+    Tn256Plan pl;
+    int algo = gemm_algo_override();
+    if (algo == 0) algo = (M >= 4096 && Kd >= 128 && Nd >= 128) ? 2 : 1;
+    pl.use256 = algo == 2;
+    pl.tiles_k = chb_div_up(Kd, 256); pl.tiles_n = chb_div_up(Nd, 256);
+    const int tiles = pl.tiles_k * pl.tiles_n;
+    const int steps = M / 64;
+    int splits = num_cus() / tiles;          // one work item per CU
+    if (splits < 1) splits = 1;
+    if (splits > steps) splits = steps;
+    pl.steps_per_split = chb_div_up(steps, splits);
+    pl.splits = chb_div_up(steps, pl.steps_per_split);
+    // partial planes + one fold launch when the caller lends enough scratch (and the fold's float4 accesses are aligned)
+    const int64_t need = (int64_t)pl.splits * Kd * Nd * 4;
+    const char* e = getenv("CHB_TN_ATOMICS");     // 1 = always the atomic epilogue (A/B timing)
+    pl.planes = pl.use256 && workspace && workspace_bytes >= need && pl.splits > 1 && !(Nd & 3) && !(ldw & 3) &&
+                !((uintptr_t)workspace & 15) && !((uintptr_t)dW & 15) && !(e && atoi(e) == 1);
+    return pl;
+}
+
+int chb_gemm_tn_fold(const float* workspace, int64_t workspace_bytes, float* dW, int64_t ldw, int M, int Kd, int Nd, void* stream) {
+    if (!dW || M < 0 || Kd <= 0 || Nd <= 0) return CHB_EINVAL;
+    if (M == 0 || M % 64 != 0) return M == 0 ? CHB_OK : CHB_EUNSUPPORTED;
+    const Tn256Plan pl = tn256_plan(M, Kd, Nd, workspace, workspace_bytes, dW, ldw);
+    if (!pl.planes) return CHB_OK;             // the GEMM took the atomic epilogue: nothing to fold
+    const int64_t quads = (int64_t)Kd * (Nd / 4);
+    const int64_t blocks = (quads + 255) / 256;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, workspace,
+                       pl.splits, Kd, Nd, dW, ldw);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int M, int Kd, int Nd,
+                   float* workspace, int64_t workspace_bytes, int fold, void* stream) {
     if (!X || !dY || !dW || M < 0 || Kd <= 0 || Nd <= 0) return CHB_EINVAL;
     if (M == 0) return CHB_OK;
     if (M % 64 != 0 || (Kd & 7) || (Nd & 7) || (ldx & 7) || (ldy & 7)) return CHB_EUNSUPPORTED;
     if (((uintptr_t)X & 15) || ((uintptr_t)dY & 15)) return CHB_EINVAL;
     {
-        int algo = gemm_algo_override();
-        if (algo == 0) algo = (M >= 4096 && Kd >= 128 && Nd >= 128) ? 2 : 1;
-        if (algo == 2) {
+        const Tn256Plan pl = tn256_plan(M, Kd, Nd, workspace, workspace_bytes, dW, ldw);
+        if (pl.use256) {
             Tn256Params q;
             q.X = (const bf16_t*)X; q.ldx = ldx; q.Y = (const bf16_t*)dY; q.ldy = ldy; q.W = dW; q.ldw = ldw;
             q.M = M; q.Kd = Kd; q.Nd = Nd;
-            q.tiles_k = chb_div_up(Kd, 256); q.tiles_n = chb_div_up(Nd, 256);
-            const int tiles = q.tiles_k * q.tiles_n;
-            const int steps = M / 64;
-            int splits = num_cus() / tiles;          // one work item per CU
-            if (splits < 1) splits = 1;
-            if (splits > steps) splits = steps;
-            q.steps_per_split = chb_div_up(steps, splits);
-            q.splits = chb_div_up(steps, q.steps_per_split);
-            hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * q.splits), dim3(512), 0, (hipStream_t)stream, q);
+            q.tiles_k = pl.tiles_k; q.tiles_n = pl.tiles_n;
+            q.steps_per_split = pl.steps_per_split;
+            q.splits = pl.splits;
+            q.ws = pl.planes ? workspace : nullptr;
+            hipLaunchKernelGGL(gemm_tn256_kernel, dim3(pl.tiles_k * pl.tiles_n * q.splits), dim3(512), 0, (hipStream_t)stream, q);
             CHB_LAUNCH_CHECK();
+            if (pl.planes && fold) return chb_gemm_tn_fold(workspace, workspace_bytes, dW, ldw, M, Kd, Nd, stream);
             return CHB_OK;
         }
     }

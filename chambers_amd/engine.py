@@ -494,6 +494,8 @@ class ViTEngine:
             self.dh = z(Mp, d)
             self.do = z(Mp, d)
             self.dqkv = z(Mp, 3 * d)
+            # scratch for the split-K partial planes of the weight-gradient GEMMs (one launch at a time on the stream)
+            self.tn_ws = torch.empty(max(K.tn_workspace_elems(*sp.shape) for sp in self.specs if sp.matrix), dtype=f32, device=dev)
             self.dpatch = z(self.Mpatch_p, d)
             self.labels = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
 
@@ -647,7 +649,7 @@ class ViTEngine:
         elif cfg.include_top:
             if doutput is not None:
                 raise ValueError("doutput is for include_top=False models; with a top the gradient comes from loss()")
-            K.gemm_tn(self.feat_b if F else self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp)
+            K.gemm_tn(self.feat_b if F else self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp, ws=self.tn_ws)
             K.colsum(self.dlogits, self.g("predictions/bias"), m=self.B)
             K.gemm_nt(self.dlogits, self.wb("predictions/kernel"), self.dfeat if F else self.dhf, m=self.B)
         elif cfg.pooling == "none":
@@ -660,7 +662,7 @@ class ViTEngine:
             (self.dfeat[:self.B, :F] if F else self.dhf[:self.B]).copy_(doutput)
         if F:
             K.tanh_bwd(self.dfeat, self.feat, self.dfz)
-            K.gemm_tn(self.hf, self.dfz, self.g("feature/kernel"), m=self.Bp)
+            K.gemm_tn(self.hf, self.dfz, self.g("feature/kernel"), m=self.Bp, ws=self.tn_ws)
             K.colsum(self.dfz, self.g("feature/bias"), m=self.B)
             K.gemm_nt(self.dfz, self.wb("feature/kernel"), self.dhf, m=self.B)
         # pooling + final norm
@@ -686,16 +688,16 @@ class ViTEngine:
             a = self.acts[l]
             pre = "encoder/layer_%d/" % l
             # MLP branch (self.dz = dropout-backward of dx at site_mlp(l))
-            K.gemm_tn(a["u"], self.dz, self.g(pre + "dense2/kernel"), m=Mp)
+            K.gemm_tn(a["u"], self.dz, self.g(pre + "dense2/kernel"), m=Mp, ws=self.tn_ws)
             K.gemm_nt(self.dz, self.wb(pre + "dense2/kernel"), self.da1, m=M, epilogue=K.EPI_DGELU, aux=a["a1"],
                       colsum=self.g(pre + "dense1/bias"))           # bias gradient of dense1 fused into the epilogue
-            K.gemm_tn(a["h2"], self.da1, self.g(pre + "dense1/kernel"), m=Mp)
+            K.gemm_tn(a["h2"], self.da1, self.g(pre + "dense1/kernel"), m=Mp, ws=self.tn_ws)
             K.gemm_nt(self.da1, self.wb(pre + "dense1/kernel"), self.dh, m=M)
             K.layernorm_bwd(self.dh, a["xmid"], d, a["mean2"], a["rstd2"], self.p(pre + "norm2/gamma"), self.dx, d, True,
                             self.g(pre + "norm2/gamma"), self.g(pre + "norm2/beta"), M, d, dz=self.dz,
                             dz_colsum=self.g(pre + "proj/bias"), drop_rate=rate, drop_key=key(rng.site_proj(l)))
             # attention branch (self.dz = dropout-backward of dx at site_proj(l))
-            K.gemm_tn(a["o"], self.dz, self.g(pre + "proj/kernel"), m=Mp)
+            K.gemm_tn(a["o"], self.dz, self.g(pre + "proj/kernel"), m=Mp, ws=self.tn_ws)
             K.gemm_nt(self.dz, self.wb(pre + "proj/kernel"), self.do, m=M)
             # this block's MLP / projection gradients and the previous block's QKV gradients are final and adjacent in the flat
             # buffer: one all-reduce, started beside the attention backward
@@ -703,7 +705,7 @@ class ViTEngine:
             self.reducer.flush()
             K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], self.dqkv, self.B, n, cfg.n_heads, cfg.head_dim, rate,
                             key(rng.site_attn(l)))
-            K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp)
+            K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp, ws=self.tn_ws)
             # (attention_bwd can fuse this sum via dbias=: measured 0.99 ms against 0.69 + 0.09 ms for the stand-alone streaming pass
             #  at 197 tokens — the four extra accumulators and the cross-wave fold make the 128-register kernel spill)
             K.colsum(self.dqkv, self.g(pre + "qkv/bias"), m=M)
@@ -720,7 +722,7 @@ class ViTEngine:
         # embedding stage
         K.embed_bwd(self.dx, self.dpatch, self.g("pos_embedding/embeddings"), self.g("add_cls_token/embeddings"), self.B, n, d, rate,
                     key(rng.SITE_EMBED), n_special=cfg.n_special)
-        K.gemm_tn(self.patches, self.dpatch, self.g("patch_embeddings/embedding/kernel"), m=self.Mpatch_p)
+        K.gemm_tn(self.patches, self.dpatch, self.g("patch_embeddings/embedding/kernel"), m=self.Mpatch_p, ws=self.tn_ws)
         K.colsum(self.dpatch, self.g("patch_embeddings/embedding/bias"), m=self.Mpatch)
         self.reducer.bucket_ready(2 * L + 1)
         self.reducer.flush()
@@ -742,10 +744,10 @@ class ViTEngine:
         if cfg.include_top:
             self.dlogits[:self.B, :cfg.classes].copy_(da)
             self.dlogits_dist[:self.B, :cfg.classes].copy_(db)
-            K.gemm_tn(self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp)
+            K.gemm_tn(self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp, ws=self.tn_ws)
             K.colsum(self.dlogits, self.g("predictions/bias"), m=self.B)
             K.gemm_nt(self.dlogits, self.wb("predictions/kernel"), self.dhf, m=self.B)
-            K.gemm_tn(self.hfd, self.dlogits_dist, self.g("predictions_dist/kernel"), m=self.Bp)
+            K.gemm_tn(self.hfd, self.dlogits_dist, self.g("predictions_dist/kernel"), m=self.Bp, ws=self.tn_ws)
             K.colsum(self.dlogits_dist, self.g("predictions_dist/bias"), m=self.B)
             K.gemm_nt(self.dlogits_dist, self.wb("predictions_dist/kernel"), self.dhfd, m=self.B)
         else:

@@ -237,13 +237,37 @@ def gemm_nt(a, b, out, m=None, bias=None, epilogue=EPI_NONE, aux=None, resid=Non
     return out
 
 
-def gemm_tn(x, dy, dw, m=None):
-    """dw[Kd,Nd] += x[M,Kd]^T . dy[M,Nd] (fp32 accumulate)."""
-    _lib.require_gpu(x, dy, dw)
+def gemm_tn(x, dy, dw, m=None, ws=None, fold=True):
+    """dw[Kd,Nd] += x[M,Kd]^T . dy[M,Nd] (fp32 accumulate).  ws: optional fp32 scratch tensor for the split-K partial planes
+    (tn_workspace_elems(Kd, Nd) elements suffice); without it the partials meet in fp32 atomics.  fold=False leaves the planes
+    in ws until gemm_tn_fold (same arguments)."""
+    _lib.require_gpu(x, dy, dw, ws)
     m = x.shape[0] if m is None else m
-    _lib.call("chb_gemm_tn", _lib.ptr(x), x.stride(0), _lib.ptr(dy), dy.stride(0), _lib.ptr(dw), dw.stride(0), int(m), x.shape[1], dy.shape[1],
-              _s())
+    if ws is None:
+        _lib.call("chb_gemm_tn", _lib.ptr(x), x.stride(0), _lib.ptr(dy), dy.stride(0), _lib.ptr(dw), dw.stride(0), int(m), x.shape[1],
+                  dy.shape[1], _s())
+    else:
+        if ws.dtype != torch.float32:
+            raise ValueError("ws must be fp32")
+        _lib.call("chb_gemm_tn_ws", _lib.ptr(x), x.stride(0), _lib.ptr(dy), dy.stride(0), _lib.ptr(dw), dw.stride(0), int(m), x.shape[1],
+                  dy.shape[1], _lib.ptr(ws), int(ws.numel()) * 4, 1 if fold else 0, _s())
     return dw
+
+
+def gemm_tn_fold(x, dy, dw, m=None, ws=None):
+    """Second half of gemm_tn(..., ws=ws, fold=False): dw += sum of the partial planes (no-op if that call used atomics)."""
+    if ws is None:
+        return dw
+    _lib.require_gpu(dw, ws)
+    m = x.shape[0] if m is None else m
+    _lib.call("chb_gemm_tn_fold", _lib.ptr(ws), int(ws.numel()) * 4, _lib.ptr(dw), dw.stride(0), int(m), x.shape[1], dy.shape[1], _s())
+    return dw
+
+
+def tn_workspace_elems(kd, nd, n_cus=256):
+    """fp32 elements that always suffice as gemm_tn scratch for a [kd, nd] gradient: one plane per split, splits <= CUs / tiles."""
+    tiles = ((kd + 255) // 256) * ((nd + 255) // 256)
+    return max(1, n_cus // tiles) * kd * nd
 
 
 def layernorm_fwd(x, x_stride, gamma, beta, y, mean, rstd, m, d, eps):

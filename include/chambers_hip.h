@@ -121,6 +121,15 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
  * into dW (caller zeroes it once per step).  M % 64 == 0 (pad rows must be zero). */
 int chb_gemm_tn(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int M, int Kd, int Nd,
                 void* stream);
+/* The same with caller-lent scratch: when `workspace_bytes` >= splits * Kd * Nd * 4 (splits <= number of CUs / number of 256x256
+ * output tiles; Kd * Nd * 4 * 256 / tiles bytes always suffice) every split-K work item stores its partial tile with plain
+ * 16-byte stores and a second small launch folds the planes into dW, instead of meeting in fp32 atomics (the atomic tail was
+ * ~50 us of a 380 us launch).  Falls back to the atomic epilogue when the scratch is too small or misaligned. */
+int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int M, int Kd, int Nd,
+                   float* workspace, int64_t workspace_bytes, int fold, void* stream);
+/* fold != 0 above folds right away; with fold == 0 the planes stay in the scratch until this call (same arguments), e.g. to
+ * bracket the GEMM launch alone with events.  A no-op when the GEMM of these arguments takes the atomic epilogue. */
+int chb_gemm_tn_fold(const float* workspace, int64_t workspace_bytes, float* dW, int64_t ldw, int M, int Kd, int Nd, void* stream);
 
 /* keras LayerNormalization over the last axis (layers/transformer.py:39,49,283): x fp32 rows at
  * stride x_stride, y bf16 [M,D]; mean/rstd fp32 [M] saved for backward. D % 4 == 0, D <= 1024. */

@@ -191,6 +191,31 @@ def test_gemm_tn(m, kd, nd):
         assert torch.equal(o.cpu(), dy[:kd].float())
 
 
+@pytest.mark.parametrize("m,kd,nd", [(8192, 768, 768), (197 * 64, 192, 768), (4096, 200, 328), (12800, 768, 3072)])
+def test_gemm_tn_partial_planes_match_the_atomic_epilogue(m, kd, nd):
+    """chb_gemm_tn_ws: split-K partial planes in caller scratch + fold launch == the atomic epilogue (same products, another
+    summation order), accumulates into dW, falls back to atomics when the scratch is too small, stays inside its planes."""
+    from chambers_amd import kernels as K
+    x = bf(torch.randn(m, kd, generator=g(22))).cuda()
+    dy = bf(torch.randn(m, nd, generator=g(23))).cuda()
+    ref = x.double().cpu().t() @ dy.double().cpu()
+    need = K.tn_workspace_elems(kd, nd)
+    ws = torch.full((need + 1024,), float("nan"), device="cuda")
+    dw = torch.ones(kd, nd, dtype=torch.float32, device="cuda")
+    K.gemm_tn(x, dy, dw, ws=ws)
+    assert rel_l2(dw.cpu() - 1.0, ref) < 5e-6
+    assert bool(torch.isnan(ws[need:]).all())                     # nothing written past the planes
+    K.gemm_tn(x, dy, dw, ws=ws)                                   # accumulates
+    assert rel_l2(dw.cpu() - 1.0, 2 * ref) < 5e-6
+    atom = torch.zeros(kd, nd, dtype=torch.float32, device="cuda")
+    K.gemm_tn(x, dy, atom)
+    assert rel_l2(atom.cpu(), ref) < 5e-6
+    small = torch.full((16,), float("nan"), device="cuda")        # too small: atomic epilogue, scratch untouched
+    o = torch.zeros(kd, nd, dtype=torch.float32, device="cuda")
+    K.gemm_tn(x, dy, o, ws=small)
+    assert rel_l2(o.cpu(), ref) < 5e-6 and bool(torch.isnan(small).all())
+
+
 # ------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("m,d", [(7, 192), (197 * 2, 768), (33, 1024), (5, 384), (1, 64)])
 def test_layernorm_fwd_bwd(m, d):

@@ -41,4 +41,7 @@ if which in ("all", "tn"):
         dy = torch.randn(m, nd, device="cuda").to(torch.bfloat16)
         dw = torch.zeros(kd, nd, device="cuda")
         ms = timeit(lambda: K.gemm_tn(x, dy, dw))
-        print("%-10s M=%d Kd=%d Nd=%d  %.3f ms  %.1f TF/s" % (name, m, kd, nd, ms, 2.0 * m * kd * nd / ms / 1e9), flush=True)
+        ws = torch.empty(K.tn_workspace_elems(kd, nd), device="cuda")
+        ms2 = timeit(lambda: K.gemm_tn(x, dy, dw, ws=ws))      # partial planes + fold launch (both launches timed)
+        print("%-10s M=%d Kd=%d Nd=%d  atomics %.3f ms  %.1f TF/s   planes+fold %.3f ms  %.1f TF/s"
+              % (name, m, kd, nd, ms, 2.0 * m * kd * nd / ms / 1e9, ms2, 2.0 * m * kd * nd / ms2 / 1e9), flush=True)
