@@ -109,13 +109,21 @@ __device__ __forceinline__ float dgelu_f(float x) {
     const float cdf = 0.5f * (1.0f + copysignf(e, x));
     return cdf + x * 0.39894228040143267794f * ex;   // ex = exp(-x^2/2)
 }
-// both at once (shared erf / exp): y = gelu(x), d = gelu'(x)
+// both at once (shared erf / exp): y = gelu(x), d = gelu'(x).  Written on the normal CDF directly: with h = 0.5 * erfc(|x| / sqrt 2)
+// (the A&S polynomial with halved coefficients), cdf = 1 - h for x >= 0 and h otherwise; 1 + p z is one FMA on |x|.
 __device__ __forceinline__ void gelu_both(float x, float& y, float& d) {
-    float e, ex;
-    erf_parts(x, e, ex);
-    const float cdf = 0.5f * (1.0f + copysignf(e, x));
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+    const float ex = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.44269504088896340736f));     // exp(-x^2 / 2)
+    float poly = 0.5f * 1.061405429f;
+    poly = poly * t - 0.5f * 1.453152027f;
+    poly = poly * t + 0.5f * 1.421413741f;
+    poly = poly * t - 0.5f * 0.284496736f;
+    poly = poly * t + 0.5f * 0.254829592f;
+    const float h = (poly * t) * ex;
+    const float cdf = x >= 0.0f ? 1.0f - h : h;
     y = x * cdf;
-    d = cdf + x * 0.39894228040143267794f * ex;
+    d = cdf + (x * 0.39894228040143267794f) * ex;
 }
 
 static inline int chb_div_up(long a, long b) { return (int)((a + b - 1) / b); }
