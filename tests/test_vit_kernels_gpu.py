@@ -160,6 +160,50 @@ def test_gemm_nt_fused_column_sums(m, n, k):
     assert rel_l2((cs - 3.0).cpu(), ref.sum(0)) < 2e-3       # sums of fp32 (fused) or bf16-rounded (stand-alone) outputs
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_gemm_shape_fuzz(seed):
+    """Seeded random shapes through both GEMM forms: tile edges in M and N, 1-13 K-tiles, the persistent 256x256 kernels (M >=
+    2048 / 4096) and the small-shape kernels, plain / GELU / residual epilogues, bf16 and fp32 outputs, partial-plane and atomic
+    weight gradients — against a float64 product of the same bf16 operands."""
+    from chambers_amd import kernels as K
+    r = np.random.default_rng(1000 + seed)
+    m = int(r.choice([r.integers(1, 300), r.integers(2048, 6000), r.integers(4096, 9000)]))
+    n = int(r.integers(1, 140)) * 8
+    k = int(r.integers(1, 14)) * 64
+    a = bf(torch.randn(m, k, generator=g(200 + seed))).cuda()
+    b = bf(torch.randn(n, k, generator=g(300 + seed)) * 0.1).cuda()
+    bias = torch.randn(n, generator=g(400 + seed)).cuda()
+    ref = a.double().cpu() @ b.double().cpu().t() + bias.double().cpu()
+    epi = int(r.integers(0, 3))
+    out_f32 = bool(r.integers(0, 2))
+    out = torch.full((m + 3, n), 9.0, dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    if epi == 0:
+        K.gemm_nt(a, b, out, m=m, bias=bias)
+    elif epi == 1:
+        aux = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+        K.gemm_nt(a, b, out, m=m, bias=bias, epilogue=K.EPI_GELU, aux=aux)
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2.0)))
+    else:
+        resid = torch.randn(m, n, generator=g(500 + seed)).cuda()
+        out = torch.full((m + 3, n), 9.0, dtype=torch.float32, device="cuda")
+        K.gemm_nt(a, b, out, m=m, bias=bias, epilogue=K.EPI_RESID, resid=resid)
+        ref = ref + resid.double().cpu()
+        out_f32 = True
+    assert rel_l2(out[:m].float().cpu(), ref) < (1e-5 if out_f32 else 4e-3), (m, n, k, epi)
+    assert bool((out[m:].float() == 9.0).all()), "rows past M were written"
+    # weight gradient of the same operands: dW[k, n] = A^T . (A-shaped dY) needs M % 64 == 0
+    mp = (m + 63) // 64 * 64
+    x = torch.zeros(mp, k, dtype=torch.bfloat16, device="cuda")
+    x[:m] = a
+    dy = torch.zeros(mp, n, dtype=torch.bfloat16, device="cuda")
+    dy[:m] = bf(torch.randn(m, n, generator=g(600 + seed))).cuda()
+    wref = x.double().cpu().t() @ dy.double().cpu()
+    for ws in (None, torch.empty(K.tn_workspace_elems(k, n), device="cuda")):
+        dw = torch.zeros(k, n, device="cuda")
+        K.gemm_tn(x, dy, dw, m=mp, ws=ws)
+        assert rel_l2(dw.cpu(), wref) < 5e-6, (mp, k, n, ws is None)
+
+
 def test_gemm_nt_rejects_bad_shapes():
     from chambers_amd import kernels as K
     a = torch.zeros(8, 48, dtype=torch.bfloat16, device="cuda")
