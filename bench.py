@@ -66,13 +66,13 @@ class KernelTimer:
             timer.records.append((name, 2.0 * mm * b.shape[0] * b.shape[1], s, e))
             return r
 
-        def gemm_tn(x, dy, dw, m=None, ws=None, fold=True):
+        def gemm_tn(x, dy, dw, m=None, ws=None, fold=True, colsum=None):
             if not timer.enabled:
-                return orig_tn(x, dy, dw, m=m, ws=ws, fold=fold)
+                return orig_tn(x, dy, dw, m=m, ws=ws, fold=fold, colsum=colsum)
             mm = x.shape[0] if m is None else m
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = orig_tn(x, dy, dw, m=m, ws=ws, fold=False)      # the GEMM launch alone sits between the events ...
+            r = orig_tn(x, dy, dw, m=m, ws=ws, fold=False, colsum=colsum)      # the GEMM launch alone sits between the events ...
             e.record()
             if fold:
                 K.gemm_tn_fold(x, dy, dw, m=m, ws=ws)           # ... the fold of its partial planes (tn_reduce_kernel) follows

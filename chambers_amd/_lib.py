@@ -38,7 +38,7 @@ PROTOTYPES = {
     "chb_gemm_nt": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P, c_int, c_int, P, c_int64, P, c_int64,
                     c_int, c_float, c_uint32, P, P],
     "chb_gemm_tn": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P],
-    "chb_gemm_tn_ws": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P, c_int64, c_int, P],
+    "chb_gemm_tn_ws": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P, c_int64, c_int, P, P],
     "chb_gemm_tn_fold": [P, c_int64, P, c_int64, c_int, c_int, c_int, P],
     "chb_layernorm_fwd": [P, c_int64, P, P, P, P, P, c_int, c_int, c_float, P],
     "chb_layernorm_bwd": [P, P, c_int64, P, P, P, P, c_int64, c_int, P, P, c_int, c_int, P, P, c_float, c_uint32, P],

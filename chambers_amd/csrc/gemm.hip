@@ -926,6 +926,7 @@ struct Tn256Params {
     int tiles_k, tiles_n, splits, steps_per_split;
     float* ws;        // optional [splits][Kd][Nd] fp32: every work item stores its partial tile there (plain 16-byte stores) and
                       // tn_reduce_kernel folds the planes into W; without it the partials meet in fp32 atomics on W
+    float* colsum;    // COLSUM instantiation: fp32 [Nd] += column sums of dY (the bias gradient of the layer), see the kernel
 };
 
 __device__ __forceinline__ void stage_half_tn(const bf16_t* __restrict__ g, int64_t ld, int m0, int col0, int ncols, bf16_t* lds_half,
@@ -941,6 +942,11 @@ __device__ __forceinline__ void stage_half_tn(const bf16_t* __restrict__ g, int6
     }
 }
 
+// COLSUM: the column sums of dY over M (= ones^T . dY, the bias gradient) ride along as one more MFMA per dY fragment with an
+// all-ones X fragment, in the waves of the first kd half (wk == 0) of the workgroups of the first kd tile (tk == 0): 8 MFMAs on
+// top of 128 per SIMD and K-tile there, instead of a separate HBM pass over dY (465 MB for the QKV projection).  A separate
+// instantiation, so the plain kernel keeps its registers and schedule.
+template <bool COLSUM>
 __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * 8192 + 8 * 2048];
     const int tid = threadIdx.x;
@@ -982,6 +988,15 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+    float4_t cacc[4];
+    const bool do_colsum = COLSUM && tk == 0 && wk == 0;      // wave-uniform
+    bf16x8_t ones;
+    if (COLSUM) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cacc[b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        const short8_t o8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
+        ones = __builtin_bit_cast(bf16x8_t, o8);
+    }
     const int ycol = (wn & 1) * 64;   // + nq*32 + b*16 within the wave's dY half
     // Lane-constant LDS element offsets of the transposed reads.  For row r0 = 8g + q the swizzle is the same at r0 + 4 and
     // r0 + 32, so one base per 16-column tile serves its four reads (rows +0, +4, +32, +36) with compile-time offsets.
@@ -1024,6 +1039,12 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][ks], xf[a][ks], acc[a][b], 0, 0, 0);
+        if (COLSUM && do_colsum) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) cacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][ks], ones, cacc[b], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // (no barrier: phase 2 restages the OTHER ring's X slots and reads this ring's dY slots, nothing phase 1 still reads)
@@ -1043,6 +1064,12 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][ks], xf[a][ks], acc[a][2 + b], 0, 0, 0);
+        if (COLSUM && do_colsum) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) cacc[2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][ks], ones, cacc[2 + b], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -1090,6 +1117,18 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 
     // acc[a][b][r]: kd = k0 + wk*128 + a*16 + i, nd = n0 + wn*64 + b*16 + 4g + r.  Stage one 16(kd) x 64(nd) tile row
     // at a time and add it as 16 full 256-byte rows.
+    if (COLSUM && do_colsum) {
+        // cacc[b][r] = sum over this split's rows of dY[:, n0 + wn*64 + b*16 + 4g + r], replicated over the 16 lanes i
+        if (i == 0) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ndc = n0 + wn * 64 + b * 16 + 4 * g + r;
+                    if (ndc < p.Nd) atomicAdd(p.colsum + ndc, cacc[b][r]);
+                }
+        }
+    }
     float* stage = reinterpret_cast<float*>(smem + 2 * 4 * 8192) + wave * 1024;
     if (p.ws) {
         // partial plane of this split: lane = (row r4 + 4k of the tile row, 4 columns) -> 4 rows x 256 bytes per store instruction
@@ -1252,7 +1291,7 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
 
 int chb_gemm_tn(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int M, int Kd, int Nd,
                 void* stream) {
-    return chb_gemm_tn_ws(X, ldx, dY, ldy, dW, ldw, M, Kd, Nd, nullptr, 0, 1, stream);
+    return chb_gemm_tn_ws(X, ldx, dY, ldy, dW, ldw, M, Kd, Nd, nullptr, 0, 1, nullptr, stream);
 }
 
 // split plan of the persistent 256x256 weight-gradient kernel; `planes`: partial planes in caller scratch instead of atomics
@@ -1293,7 +1332,7 @@ int chb_gemm_tn_fold(const float* workspace, int64_t workspace_bytes, float* dW,
 }
 
 int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int M, int Kd, int Nd,
-                   float* workspace, int64_t workspace_bytes, int fold, void* stream) {
+                   float* workspace, int64_t workspace_bytes, int fold, float* dy_colsum, void* stream) {
     if (!X || !dY || !dW || M < 0 || Kd <= 0 || Nd <= 0) return CHB_EINVAL;
     if (M == 0) return CHB_OK;
     if (M % 64 != 0 || (Kd & 7) || (Nd & 7) || (ldx & 7) || (ldy & 7)) return CHB_EUNSUPPORTED;
@@ -1308,7 +1347,9 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
             q.steps_per_split = pl.steps_per_split;
             q.splits = pl.splits;
             q.ws = pl.planes ? workspace : nullptr;
-            hipLaunchKernelGGL(gemm_tn256_kernel, dim3(pl.tiles_k * pl.tiles_n * q.splits), dim3(512), 0, (hipStream_t)stream, q);
+            q.colsum = dy_colsum;
+            if (dy_colsum) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(pl.tiles_k * pl.tiles_n * q.splits), dim3(512), 0, (hipStream_t)stream, q);
+            else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(pl.tiles_k * pl.tiles_n * q.splits), dim3(512), 0, (hipStream_t)stream, q);
             CHB_LAUNCH_CHECK();
             if (pl.planes && fold) return chb_gemm_tn_fold(workspace, workspace_bytes, dW, ldw, M, Kd, Nd, stream);
             return CHB_OK;
@@ -1327,6 +1368,7 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
     p.splits = chb_div_up(steps, p.steps_per_split);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * p.splits), dim3(256), 0, (hipStream_t)stream, p);
     CHB_LAUNCH_CHECK();
+    if (dy_colsum) return chb_colsum_bf16(dY, ldy, dy_colsum, M, Nd, stream);     // small shapes: the stand-alone pass
     return CHB_OK;
 }
 

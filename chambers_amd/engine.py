@@ -705,10 +705,10 @@ class ViTEngine:
             self.reducer.flush()
             K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], self.dqkv, self.B, n, cfg.n_heads, cfg.head_dim, rate,
                             key(rng.site_attn(l)))
-            K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp, ws=self.tn_ws)
-            # (attention_bwd can fuse this sum via dbias=: measured 0.99 ms against 0.69 + 0.09 ms for the stand-alone streaming pass
-            #  at 197 tokens — the four extra accumulators and the cross-wave fold make the 128-register kernel spill)
-            K.colsum(self.dqkv, self.g(pre + "qkv/bias"), m=M)
+            # the QKV bias gradient (column sums of dqkv) rides along in the weight-gradient GEMM as ones^T . dqkv: +5 % on that
+            # launch instead of a 0.09 ms pass over dqkv (attention_bwd can also fuse it via dbias=, but its four extra
+            # accumulators and the cross-wave fold make the 128-register kernel spill: 0.99 ms against 0.69)
+            K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp, ws=self.tn_ws, colsum=self.g(pre + "qkv/bias"))
             K.gemm_nt(self.dqkv, self.wb(pre + "qkv/kernel"), self.dh, m=M)
             if l > 0:
                 K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
@@ -722,8 +722,8 @@ class ViTEngine:
         # embedding stage
         K.embed_bwd(self.dx, self.dpatch, self.g("pos_embedding/embeddings"), self.g("add_cls_token/embeddings"), self.B, n, d, rate,
                     key(rng.SITE_EMBED), n_special=cfg.n_special)
-        K.gemm_tn(self.patches, self.dpatch, self.g("patch_embeddings/embedding/kernel"), m=self.Mpatch_p, ws=self.tn_ws)
-        K.colsum(self.dpatch, self.g("patch_embeddings/embedding/bias"), m=self.Mpatch)
+        K.gemm_tn(self.patches, self.dpatch, self.g("patch_embeddings/embedding/kernel"), m=self.Mpatch_p, ws=self.tn_ws,
+                  colsum=self.g("patch_embeddings/embedding/bias"))
         self.reducer.bucket_ready(2 * L + 1)
         self.reducer.flush()
 

@@ -237,20 +237,22 @@ def gemm_nt(a, b, out, m=None, bias=None, epilogue=EPI_NONE, aux=None, resid=Non
     return out
 
 
-def gemm_tn(x, dy, dw, m=None, ws=None, fold=True):
+def gemm_tn(x, dy, dw, m=None, ws=None, fold=True, colsum=None):
     """dw[Kd,Nd] += x[M,Kd]^T . dy[M,Nd] (fp32 accumulate).  ws: optional fp32 scratch tensor for the split-K partial planes
     (tn_workspace_elems(Kd, Nd) elements suffice); without it the partials meet in fp32 atomics.  fold=False leaves the planes
-    in ws until gemm_tn_fold (same arguments)."""
-    _lib.require_gpu(x, dy, dw, ws)
+    in ws until gemm_tn_fold (same arguments).  colsum (fp32 [Nd]): += column sums of dy (bias gradient), inside the GEMM."""
+    _lib.require_gpu(x, dy, dw, ws, colsum)
     m = x.shape[0] if m is None else m
-    if ws is None:
+    if ws is None and colsum is None:
         _lib.call("chb_gemm_tn", _lib.ptr(x), x.stride(0), _lib.ptr(dy), dy.stride(0), _lib.ptr(dw), dw.stride(0), int(m), x.shape[1],
                   dy.shape[1], _s())
     else:
-        if ws.dtype != torch.float32:
+        if ws is not None and ws.dtype != torch.float32:
             raise ValueError("ws must be fp32")
+        if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() < dy.shape[1]):
+            raise ValueError("colsum must be fp32 [Nd]")
         _lib.call("chb_gemm_tn_ws", _lib.ptr(x), x.stride(0), _lib.ptr(dy), dy.stride(0), _lib.ptr(dw), dw.stride(0), int(m), x.shape[1],
-                  dy.shape[1], _lib.ptr(ws), int(ws.numel()) * 4, 1 if fold else 0, _s())
+                  dy.shape[1], _lib.ptr(ws), (int(ws.numel()) * 4) if ws is not None else 0, 1 if fold else 0, _lib.ptr(colsum), _s())
     return dw
 
 

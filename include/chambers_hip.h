@@ -126,8 +126,10 @@ int chb_gemm_tn(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* 
  * 16-byte stores and a second small launch folds the planes into dW, instead of meeting in fp32 atomics (the atomic tail was
  * ~50 us of a 380 us launch).  Falls back to the atomic epilogue when the scratch is too small or misaligned. */
 int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int M, int Kd, int Nd,
-                   float* workspace, int64_t workspace_bytes, int fold, void* stream);
-/* fold != 0 above folds right away; with fold == 0 the planes stay in the scratch until this call (same arguments), e.g. to
+                   float* workspace, int64_t workspace_bytes, int fold, float* dy_colsum, void* stream);
+/* dy_colsum (fp32 [Nd], optional): += column sums of dY over M — the bias gradient of the same layer — computed inside the GEMM
+ * (one more MFMA per dY fragment against an all-ones fragment) instead of a separate pass over dY.
+ * fold != 0 above folds right away; with fold == 0 the planes stay in the scratch until this call (same arguments), e.g. to
  * bracket the GEMM launch alone with events.  A no-op when the GEMM of these arguments takes the atomic epilogue. */
 int chb_gemm_tn_fold(const float* workspace, int64_t workspace_bytes, float* dW, int64_t ldw, int M, int Kd, int Nd, void* stream);
 

@@ -200,8 +200,10 @@ def test_gemm_shape_fuzz(seed):
     wref = x.double().cpu().t() @ dy.double().cpu()
     for ws in (None, torch.empty(K.tn_workspace_elems(k, n), device="cuda")):
         dw = torch.zeros(k, n, device="cuda")
-        K.gemm_tn(x, dy, dw, m=mp, ws=ws)
+        cs = torch.zeros(n, device="cuda")
+        K.gemm_tn(x, dy, dw, m=mp, ws=ws, colsum=cs)
         assert rel_l2(dw.cpu(), wref) < 5e-6, (mp, k, n, ws is None)
+        assert rel_l2(cs.cpu(), dy.double().cpu().sum(0)) < 2e-5, (mp, k, n, ws is None)
 
 
 def test_gemm_nt_rejects_bad_shapes():
@@ -254,6 +256,13 @@ def test_gemm_tn_partial_planes_match_the_atomic_epilogue(m, kd, nd):
     atom = torch.zeros(kd, nd, dtype=torch.float32, device="cuda")
     K.gemm_tn(x, dy, atom)
     assert rel_l2(atom.cpu(), ref) < 5e-6
+    # column sums of dY ride along (ones^T . dY): same products as the weight gradient, with either epilogue
+    for w in (ws, None):
+        cs = torch.full((nd,), 2.0, device="cuda")
+        o = torch.zeros(kd, nd, dtype=torch.float32, device="cuda")
+        K.gemm_tn(x, dy, o, ws=w, colsum=cs)
+        assert rel_l2(o.cpu(), ref) < 5e-6
+        assert rel_l2((cs - 2.0).cpu(), dy.double().cpu().sum(0)) < 5e-6
     small = torch.full((16,), float("nan"), device="cuda")        # too small: atomic epilogue, scratch untouched
     o = torch.zeros(kd, nd, dtype=torch.float32, device="cuda")
     K.gemm_tn(x, dy, o, ws=small)
