@@ -144,10 +144,15 @@ def pmc_traffic(kernel):
     if not files:
         return None
     with open(files[-1]) as f:
-        k = json.load(f).get("kernels", {}).get(kernel)
-    if not k:
+        table = json.load(f).get("kernels", {})
+    # the live timer groups a kernel's template instantiations that the engine picks per call (gemm_tn256_kernel<false|true>:
+    # without / with the ride-along bias gradient); rocprofv3 lists them separately: launch-weighted mean over them
+    rows = [v for k, v in table.items() if k == kernel or k.startswith(kernel + "<")]
+    n = sum(v["launches_sampled"] for v in rows)
+    if not rows or not n:
         return None
-    return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": "profiles/" + os.path.basename(files[-1])}
+    return {"hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in rows) / n,
+            "source": "profiles/" + os.path.basename(files[-1])}
 
 
 def ensure_library(local_rank):
