@@ -46,6 +46,14 @@ __device__ __forceinline__ bf16x8_t lds_tr_frag(const bf16_t* img, int ra, int r
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// the same from precomputed addresses (rows ra + q / rb + q of the lane): used where the swizzle does not depend on the loop
+__device__ __forceinline__ bf16x8_t lds_tr_frag_at(const bf16_t* a0, const bf16_t* a1) {
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a0);
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a1);
+    short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 __device__ __forceinline__ bf16x8_t pack8(const float4_t& a, const float4_t& b) {
     short8_t v;
     v[0] = (short)f32_to_bf16(a[0]); v[1] = (short)f32_to_bf16(a[1]); v[2] = (short)f32_to_bf16(a[2]); v[3] = (short)f32_to_bf16(a[3]);
@@ -251,6 +259,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
             kfr[c][ks] = lds_row_frag(Ks, 16 * t + i, 4 * ks + g);
             vfr[c][ks] = lds_row_frag(Vs, 16 * t + i, 4 * ks + g);
         }
+    // Lane-constant LDS element offsets.  Query blocks start at multiples of 32 rows and key pairs at multiples of 32, so the row
+    // swizzle ((r >> 1) & 7) of every fragment row depends on the lane only: all address arithmetic leaves the block loop.
+    const int lq = i >> 2, lpp = i & 3;
+    int rowoff[2];            // row fragments of Q / dO: row (block row 16 qs) + i, chunk 4 ks + g
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) rowoff[ks] = i * HD + (((4 * ks + g) ^ swz_row(i)) << 3);
+    int troff[4];             // transposed fragments of Q / dO: rows 4g + lq (and + 16), columns 16 dt + 4 lpp ..
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) troff[dt] = (4 * g + lq) * HD + (((2 * dt + (lpp >> 1)) ^ swz_row(4 * g + lq)) << 3) + 4 * (lpp & 1);
     // round `it` runs phase A of query block `it` (scores, dS, dK/dV) and phase B of block `it - 1` (dQ from the dS tile
     // published one round earlier) between the same pair of barriers: one barrier per block instead of two
     for (int it = 0; it <= NTP; ++it) {
@@ -263,8 +280,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
         for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                qa[qs][ks] = lds_row_frag(Qs, q0 + 16 * qs + i, 4 * ks + g);
-                ga[qs][ks] = lds_row_frag(Gs, q0 + 16 * qs + i, 4 * ks + g);
+                qa[qs][ks] = *reinterpret_cast<const bf16x8_t*>(Qs + (q0 + 16 * qs) * HD + rowoff[ks]);
+                ga[qs][ks] = *reinterpret_cast<const bf16x8_t*>(Gs + (q0 + 16 * qs) * HD + rowoff[ks]);
             }
         float l2[2][4], dl[2][4];
 #pragma unroll
@@ -274,12 +291,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
                 l2[qs][r] = lse2[q0 + 16 * qs + 4 * g + r];
                 dl[qs][r] = delta[q0 + 16 * qs + 4 * g + r];
             }
+        // dropout element index ((b*H+h)*N + q)*N + key: one multiply per block, rows by adding multiples of N.  Queries and keys
+        // past N need no clamp: their probabilities are exactly zero (lse = +inf / key mask), whatever the mask bit says.
         uint32_t erow[2][4];
+        {
+            const uint32_t e0 = ((uint32_t)bh * (uint32_t)N + (uint32_t)(q0 + 4 * g)) * (uint32_t)N;
+            const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane(N);
+            erow[0][0] = e0;
+            erow[0][1] = erow[0][0] + un;
+            erow[0][2] = erow[0][1] + un;
+            erow[0][3] = erow[0][2] + un;
+            const uint32_t un16 = un << 4;
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                erow[qs][r] = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + 16 * qs + 4 * g + r, N - 1)) * (uint32_t)N;
+            for (int r = 0; r < 4; ++r) erow[1][r] = erow[0][r] + un16;
+        }
 #pragma unroll
         for (int c = 0; c < MT; ++c) {
             const int t = wave + NW * c;
@@ -303,7 +328,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
                         float keepc = 1.0f;
                         if (DROP) {
                             // element ((b*H+h)*N + q)*N + key as 32-bit arithmetic; one row base per (qs, r), one add per key
-                            const uint32_t e = erow[qs][r] + (uint32_t)min(key, N - 1);
+                            const uint32_t e = erow[qs][r] + (uint32_t)key;
                             const uint32_t hsh = chb_hash32((e >> 1) ^ drop_key);
                             const uint32_t u = (e & 1u) ? (hsh >> 16) : (hsh & 0xffffu);
                             keepc = (u >= drop_thr) ? drop_scale : 0.f;
@@ -317,8 +342,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
                 const bf16x8_t sf = pack8(ds[0], ds[1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8_t gt = lds_tr_frag<false>(Gs, q0 + 4 * g, q0 + 16 + 4 * g, 16 * dt, i);
-                    const bf16x8_t qt = lds_tr_frag<false>(Qs, q0 + 4 * g, q0 + 16 + 4 * g, 16 * dt, i);
+                    const bf16x8_t gt = lds_tr_frag_at(Gs + q0 * HD + troff[dt], Gs + (q0 + 16) * HD + troff[dt]);
+                    const bf16x8_t qt = lds_tr_frag_at(Qs + q0 * HD + troff[dt], Qs + (q0 + 16) * HD + troff[dt]);
                     dv[dt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dv[dt][c], 0, 0, 0);  // dV^T[d][key]
                     dk[dt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sf, dk[dt][c], 0, 0, 0);  // dK^T[d][key]
                 }
