@@ -83,32 +83,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact-erf GELU and its derivative (activations.py:46-56).  erf by Abramowitz-Stegun 7.1.26
-// (|abs error| <= 1.5e-7, i.e. fp32-level): one v_rcp, one v_exp and five FMAs, and the exponential
-// exp(-x^2/2) is shared with the Gaussian density the derivative needs.
-__device__ __forceinline__ void erf_parts(float x, float& erf_abs, float& expo) {
-    // z = |x| / sqrt(2); erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z)
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);          // v_rcp_f32 (1 ulp)
-    expo = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);        // v_exp_f32
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    erf_abs = 1.0f - poly * t * expo;
-}
-__device__ __forceinline__ float gelu_f(float x) {
-    float e, ex;
-    erf_parts(x, e, ex);
-    return 0.5f * x * (1.0f + copysignf(e, x));
-}
-__device__ __forceinline__ float dgelu_f(float x) {
-    float e, ex;
-    erf_parts(x, e, ex);
-    const float cdf = 0.5f * (1.0f + copysignf(e, x));
-    return cdf + x * 0.39894228040143267794f * ex;   // ex = exp(-x^2/2)
-}
+// exact-erf GELU and its derivative (activations.py:46-56).  erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e.
+// fp32-level): one v_rcp, one v_exp and five FMAs; the exponential exp(-x^2/2) is shared with the Gaussian density the
+// derivative needs.
 // both at once (shared erf / exp): y = gelu(x), d = gelu'(x).  Written on the normal CDF directly: with h = 0.5 * erfc(|x| / sqrt 2)
 // (the A&S polynomial with halved coefficients), cdf = 1 - h for x >= 0 and h otherwise; 1 + p z is one FMA on |x|.
 __device__ __forceinline__ void gelu_both(float x, float& y, float& d) {
