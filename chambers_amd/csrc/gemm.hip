@@ -397,6 +397,21 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ g, int64_t
     }
 }
 
+// The same with the address split into a wave-uniform base (SALU: tile row, k offset) and two lane-constant 32-bit byte offsets
+// (row within the half-tile x leading dimension + swizzled chunk), for half-tiles that need no row clamp: one 64-bit add per
+// LDS-DMA instruction instead of a clamp, two 32-bit multiplies and a 64-bit multiply-add per lane.
+__device__ __forceinline__ void stage_half_fast(const char* __restrict__ base, const uint32_t (&off)[2], bf16_t* lds_half, int wave) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(reinterpret_cast<const bf16_t*>(base + off[j]), lds_half + (j * 8 + wave) * 512);
+}
+
+// one staging call of the persistent kernel: fast path when rows [row0, row0 + 128) all exist
+__device__ __forceinline__ void stage_half_any(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0,
+                                               const uint32_t (&off)[2], bf16_t* lds_half, int wave, int lane) {
+    if (row0 + 128 <= max_row) stage_half_fast(reinterpret_cast<const char*>(g + (int64_t)row0 * ld + k0), off, lds_half, wave);
+    else stage_half(g, ld, row0, max_row, k0, lds_half, wave, lane);
+}
+
 template <int EPI, int OUT>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     // 128 KiB operand ring [2][A0 A1 B0 B1][128 x 64] + 8 x 4 KiB wave-private epilogue scratch = the CU's whole 160 KiB
@@ -436,21 +451,30 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     const int nmy = (w.cnt - w.slot + w.stride - 1) / w.stride;
     const int total = nmy * w.ntk;
 
+    // lane-constant byte offsets of the two LDS-DMA instructions a wave issues per half-tile (row 64 j + 8 wave + lane / 8)
+    uint32_t offa[2], offb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        offa[j] = (uint32_t)(((int64_t)r * p.lda + c * 8) * 2);
+        offb[j] = (uint32_t)(((int64_t)r * p.ldb + c * 8) * 2);
+    }
     // staging streams: A runs one step ahead of compute, B two steps ahead
     Cursor ca, cb, cc;
     cursor_set(cc, w, 0);
     cursor_set(ca, w, 0);
     cursor_set(cb, w, 0);
     // prologue: all of step 0, B halves of step 1
-    stage_half(p.A, p.lda, ca.m0, p.M, 0, smem + 0 * 8192, wave, lane);
-    stage_half(p.A, p.lda, ca.m0 + 128, p.M, 0, smem + 1 * 8192, wave, lane);
-    stage_half(p.B, p.ldb, cb.n0, p.N, 0, smem + 2 * 8192, wave, lane);
-    stage_half(p.B, p.ldb, cb.n0 + 128, p.N, 0, smem + 3 * 8192, wave, lane);
+    stage_half_any(p.A, p.lda, ca.m0, p.M, 0, offa, smem + 0 * 8192, wave, lane);
+    stage_half_any(p.A, p.lda, ca.m0 + 128, p.M, 0, offa, smem + 1 * 8192, wave, lane);
+    stage_half_any(p.B, p.ldb, cb.n0, p.N, 0, offb, smem + 2 * 8192, wave, lane);
+    stage_half_any(p.B, p.ldb, cb.n0 + 128, p.N, 0, offb, smem + 3 * 8192, wave, lane);
     cursor_next(ca, w);
     cursor_next(cb, w);
     if (cb.valid) {
-        stage_half(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, smem + (4 + 2) * 8192, wave, lane);
-        stage_half(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, smem + (4 + 3) * 8192, wave, lane);
+        stage_half_any(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, offb, smem + (4 + 2) * 8192, wave, lane);
+        stage_half_any(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, offb, smem + (4 + 3) * 8192, wave, lane);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -484,8 +508,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         // ---------------- phase 1: rows 0-63 of the wave x all 64 columns (32 MFMAs).
         // The other ring's A slots were last read in phase 2 of the previous step (before its barrier): restage them now.
         if (ca.valid) {
-            stage_half(p.A, p.lda, ca.m0, p.M, ca.kt * BK, nring + 0 * 8192, wave, lane);
-            stage_half(p.A, p.lda, ca.m0 + 128, p.M, ca.kt * BK, nring + 1 * 8192, wave, lane);
+            stage_half_any(p.A, p.lda, ca.m0, p.M, ca.kt * BK, offa, nring + 0 * 8192, wave, lane);
+            stage_half_any(p.A, p.lda, ca.m0 + 128, p.M, ca.kt * BK, offa, nring + 1 * 8192, wave, lane);
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -519,8 +543,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A and B half-tiles; step s+1 has landed
         __builtin_amdgcn_sched_barrier(0);
         if (cb.valid) {                        // this ring's B slots are free now: step s+2 goes into them
-            stage_half(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, ring + 2 * 8192, wave, lane);
-            stage_half(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, ring + 3 * 8192, wave, lane);
+            stage_half_any(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, offb, ring + 2 * 8192, wave, lane);
+            stage_half_any(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, offb, ring + 3 * 8192, wave, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
