@@ -405,14 +405,16 @@ __device__ __forceinline__ void stage_half_fast(const char* __restrict__ base, c
     for (int j = 0; j < 2; ++j) glds16(reinterpret_cast<const bf16_t*>(base + off[j]), lds_half + (j * 8 + wave) * 512);
 }
 
-// one staging call of the persistent kernel: fast path when rows [row0, row0 + 128) all exist
+// one staging call of the persistent kernel.  FAST (M % 128 == 0 and N % 128 == 0: every half-tile is full) compiles the clamp
+// path out; otherwise the fast path is taken per half-tile when rows [row0, row0 + 128) all exist
+template <bool FAST>
 __device__ __forceinline__ void stage_half_any(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0,
                                                const uint32_t (&off)[2], bf16_t* lds_half, int wave, int lane) {
-    if (row0 + 128 <= max_row) stage_half_fast(reinterpret_cast<const char*>(g + (int64_t)row0 * ld + k0), off, lds_half, wave);
+    if (FAST || row0 + 128 <= max_row) stage_half_fast(reinterpret_cast<const char*>(g + (int64_t)row0 * ld + k0), off, lds_half, wave);
     else stage_half(g, ld, row0, max_row, k0, lds_half, wave, lane);
 }
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool FAST = false>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     // 128 KiB operand ring [2][A0 A1 B0 B1][128 x 64] + 8 x 4 KiB wave-private epilogue scratch = the CU's whole 160 KiB
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * 8192 + 8 * 2048];
@@ -466,15 +468,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     cursor_set(ca, w, 0);
     cursor_set(cb, w, 0);
     // prologue: all of step 0, B halves of step 1
-    stage_half_any(p.A, p.lda, ca.m0, p.M, 0, offa, smem + 0 * 8192, wave, lane);
-    stage_half_any(p.A, p.lda, ca.m0 + 128, p.M, 0, offa, smem + 1 * 8192, wave, lane);
-    stage_half_any(p.B, p.ldb, cb.n0, p.N, 0, offb, smem + 2 * 8192, wave, lane);
-    stage_half_any(p.B, p.ldb, cb.n0 + 128, p.N, 0, offb, smem + 3 * 8192, wave, lane);
+    stage_half_any<FAST>(p.A, p.lda, ca.m0, p.M, 0, offa, smem + 0 * 8192, wave, lane);
+    stage_half_any<FAST>(p.A, p.lda, ca.m0 + 128, p.M, 0, offa, smem + 1 * 8192, wave, lane);
+    stage_half_any<FAST>(p.B, p.ldb, cb.n0, p.N, 0, offb, smem + 2 * 8192, wave, lane);
+    stage_half_any<FAST>(p.B, p.ldb, cb.n0 + 128, p.N, 0, offb, smem + 3 * 8192, wave, lane);
     cursor_next(ca, w);
     cursor_next(cb, w);
     if (cb.valid) {
-        stage_half_any(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, offb, smem + (4 + 2) * 8192, wave, lane);
-        stage_half_any(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, offb, smem + (4 + 3) * 8192, wave, lane);
+        stage_half_any<FAST>(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, offb, smem + (4 + 2) * 8192, wave, lane);
+        stage_half_any<FAST>(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, offb, smem + (4 + 3) * 8192, wave, lane);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -508,8 +510,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         // ---------------- phase 1: rows 0-63 of the wave x all 64 columns (32 MFMAs).
         // The other ring's A slots were last read in phase 2 of the previous step (before its barrier): restage them now.
         if (ca.valid) {
-            stage_half_any(p.A, p.lda, ca.m0, p.M, ca.kt * BK, offa, nring + 0 * 8192, wave, lane);
-            stage_half_any(p.A, p.lda, ca.m0 + 128, p.M, ca.kt * BK, offa, nring + 1 * 8192, wave, lane);
+            stage_half_any<FAST>(p.A, p.lda, ca.m0, p.M, ca.kt * BK, offa, nring + 0 * 8192, wave, lane);
+            stage_half_any<FAST>(p.A, p.lda, ca.m0 + 128, p.M, ca.kt * BK, offa, nring + 1 * 8192, wave, lane);
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -543,8 +545,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A and B half-tiles; step s+1 has landed
         __builtin_amdgcn_sched_barrier(0);
         if (cb.valid) {                        // this ring's B slots are free now: step s+2 goes into them
-            stage_half_any(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, offb, ring + 2 * 8192, wave, lane);
-            stage_half_any(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, offb, ring + 3 * 8192, wave, lane);
+            stage_half_any<FAST>(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, offb, ring + 2 * 8192, wave, lane);
+            stage_half_any<FAST>(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, offb, ring + 3 * 8192, wave, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -970,7 +972,21 @@ __device__ __forceinline__ void stage_half_tn(const bf16_t* __restrict__ g, int6
 // all-ones X fragment, in the waves of the first kd half (wk == 0) of the workgroups of the first kd tile (tk == 0): 8 MFMAs on
 // top of 128 per SIMD and K-tile there, instead of a separate HBM pass over dY (465 MB for the QKV projection).  A separate
 // instantiation, so the plain kernel keeps its registers and schedule.
-template <bool COLSUM>
+// FAST (Kd % 256 == 0 and Nd % 256 == 0, no column clamp anywhere): the LDS-DMA addresses are a wave-uniform base (row of the K-step,
+// column of the half-tile) + lane-constant 32-bit byte offsets instead of a 64-bit multiply-add per lane and instruction.
+template <bool FAST>
+__device__ __forceinline__ void stage_half_tn_t(const bf16_t* __restrict__ g, int64_t ld, int m0, int col0, int ncols, const uint32_t (&off)[2],
+                                                bf16_t* lds_half, int wave, int lane) {
+    if (FAST) {
+        const char* base = reinterpret_cast<const char*>(g + (int64_t)m0 * ld + col0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(reinterpret_cast<const bf16_t*>(base + off[j]), lds_half + (j * 8 + wave) * 512);
+    } else {
+        stage_half_tn(g, ld, m0, col0, ncols, lds_half, wave, lane);
+    }
+}
+
+template <bool COLSUM, bool FAST>
 __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * 8192 + 8 * 2048];
     const int tid = threadIdx.x;
@@ -992,14 +1008,24 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
     const int total = s_end - s_begin;
     if (total <= 0) return;
 
+    uint32_t offx[2] = {0, 0}, offy[2] = {0, 0};     // FAST: byte offsets of this lane's two LDS-DMA pieces (row 32 j + 4 wave + lane / 16)
+    if (FAST) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (j * 8 + wave) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ swz_tn(r);
+            offx[j] = (uint32_t)(((int64_t)r * p.ldx + c * 8) * 2);
+            offy[j] = (uint32_t)(((int64_t)r * p.ldy + c * 8) * 2);
+        }
+    }
     // prologue: all of step 0, dY halves of step 1
-    stage_half_tn(p.X, p.ldx, s_begin * 64, k0, p.Kd, smem + 0 * 8192, wave, lane);
-    stage_half_tn(p.X, p.ldx, s_begin * 64, k0 + 128, p.Kd, smem + 1 * 8192, wave, lane);
-    stage_half_tn(p.Y, p.ldy, s_begin * 64, n0, p.Nd, smem + 2 * 8192, wave, lane);
-    stage_half_tn(p.Y, p.ldy, s_begin * 64, n0 + 128, p.Nd, smem + 3 * 8192, wave, lane);
+    stage_half_tn_t<FAST>(p.X, p.ldx, s_begin * 64, k0, p.Kd, offx, smem + 0 * 8192, wave, lane);
+    stage_half_tn_t<FAST>(p.X, p.ldx, s_begin * 64, k0 + 128, p.Kd, offx, smem + 1 * 8192, wave, lane);
+    stage_half_tn_t<FAST>(p.Y, p.ldy, s_begin * 64, n0, p.Nd, offy, smem + 2 * 8192, wave, lane);
+    stage_half_tn_t<FAST>(p.Y, p.ldy, s_begin * 64, n0 + 128, p.Nd, offy, smem + 3 * 8192, wave, lane);
     if (total > 1) {
-        stage_half_tn(p.Y, p.ldy, (s_begin + 1) * 64, n0, p.Nd, smem + (4 + 2) * 8192, wave, lane);
-        stage_half_tn(p.Y, p.ldy, (s_begin + 1) * 64, n0 + 128, p.Nd, smem + (4 + 3) * 8192, wave, lane);
+        stage_half_tn_t<FAST>(p.Y, p.ldy, (s_begin + 1) * 64, n0, p.Nd, offy, smem + (4 + 2) * 8192, wave, lane);
+        stage_half_tn_t<FAST>(p.Y, p.ldy, (s_begin + 1) * 64, n0 + 128, p.Nd, offy, smem + (4 + 3) * 8192, wave, lane);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1053,7 +1079,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[a] + ks * 32 * 128);
-        if (have1) stage_half_tn(p.X, p.ldx, m1, k0, p.Kd, nring + 0 * 8192, wave, lane);
+        if (have1) stage_half_tn_t<FAST>(p.X, p.ldx, m1, k0, p.Kd, offx, nring + 0 * 8192, wave, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
         __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
@@ -1078,7 +1104,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) y1[b][ks] = frag_tn_at(Ys + yo[2 + b] + ks * 32 * 128);
-        if (have1) stage_half_tn(p.X, p.ldx, m1, k0 + 128, p.Kd, nring + 1 * 8192, wave, lane);
+        if (have1) stage_half_tn_t<FAST>(p.X, p.ldx, m1, k0 + 128, p.Kd, offx, nring + 1 * 8192, wave, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
         __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
@@ -1103,7 +1129,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[4 + a] + ks * 32 * 128);
-        if (have2) stage_half_tn(p.Y, p.ldy, m2, n0, p.Nd, ring + 2 * 8192, wave, lane);
+        if (have2) stage_half_tn_t<FAST>(p.Y, p.ldy, m2, n0, p.Nd, offy, ring + 2 * 8192, wave, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
         __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
@@ -1119,7 +1145,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 
         // phase 4: (kd 64-127, nd 0-31); retire step s+1's loads
         if (have2) {
-            stage_half_tn(p.Y, p.ldy, m2, n0 + 128, p.Nd, ring + 3 * 8192, wave, lane);
+            stage_half_tn_t<FAST>(p.Y, p.ldy, m2, n0 + 128, p.Nd, offy, ring + 3 * 8192, wave, lane);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1257,8 +1283,14 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
         int grid = num_cus() & ~7;
         if (grid < 8) grid = 8;
         const dim3 g(grid), block(512);
-        if (out_dtype == CHB_OUT_F32) hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_F32>), g, block, 0, s, p);
-        else hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_BF16>), g, block, 0, s, p);
+        const bool fast = !(p.M & 127) && !(p.N & 127);       // every half-tile full: the row-clamp staging path is compiled out
+        if (out_dtype == CHB_OUT_F32) {
+            if (fast) hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_F32, true>), g, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_F32, false>), g, block, 0, s, p);
+        } else {
+            if (fast) hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_BF16, true>), g, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_BF16, false>), g, block, 0, s, p);
+        }
         return CHB_OK;
     }
     const dim3 grid(p.tiles_m * p.tiles_n), block(256);
@@ -1372,8 +1404,17 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
             q.splits = pl.splits;
             q.ws = pl.planes ? workspace : nullptr;
             q.colsum = dy_colsum;
-            if (dy_colsum) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(pl.tiles_k * pl.tiles_n * q.splits), dim3(512), 0, (hipStream_t)stream, q);
-            else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(pl.tiles_k * pl.tiles_n * q.splits), dim3(512), 0, (hipStream_t)stream, q);
+            const dim3 grid(pl.tiles_k * pl.tiles_n * q.splits);
+            const char* fe = getenv("CHB_TN_FAST");        // 0 = generic staging addresses everywhere (A/B timing)
+            const bool fast = !(Kd & 255) && !(Nd & 255) && !(fe && atoi(fe) == 0);
+            hipStream_t st = (hipStream_t)stream;
+            if (dy_colsum) {
+                if (fast) hipLaunchKernelGGL((gemm_tn256_kernel<true, true>), grid, dim3(512), 0, st, q);
+                else hipLaunchKernelGGL((gemm_tn256_kernel<true, false>), grid, dim3(512), 0, st, q);
+            } else {
+                if (fast) hipLaunchKernelGGL((gemm_tn256_kernel<false, true>), grid, dim3(512), 0, st, q);
+                else hipLaunchKernelGGL((gemm_tn256_kernel<false, false>), grid, dim3(512), 0, st, q);
+            }
             CHB_LAUNCH_CHECK();
             if (pl.planes && fold) return chb_gemm_tn_fold(workspace, workspace_bytes, dW, ldw, M, Kd, Nd, stream);
             return CHB_OK;
