@@ -145,9 +145,11 @@ def pmc_traffic(kernel):
         return None
     with open(files[-1]) as f:
         table = json.load(f).get("kernels", {})
-    # the live timer groups a kernel's template instantiations that the engine picks per call (gemm_tn256_kernel<false|true>:
-    # without / with the ride-along bias gradient); rocprofv3 lists them separately: launch-weighted mean over them
-    rows = [v for k, v in table.items() if k == kernel or k.startswith(kernel + "<")]
+    # the live timer groups a kernel's template instantiations that are picked per call (gemm_tn256_kernel<COLSUM, FAST>: with /
+    # without the ride-along bias gradient; trailing FAST = staging without clamps, gemm_nt256_kernel<EPI, OUT, FAST>); rocprofv3
+    # lists them separately: launch-weighted mean over them
+    rows = [v for k, v in table.items()
+            if k == kernel or k.startswith(kernel + "<") or (kernel.endswith(">") and k.startswith(kernel[:-1] + ","))]
     n = sum(v["launches_sampled"] for v in rows)
     if not rows or not n:
         return None
