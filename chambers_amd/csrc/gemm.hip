@@ -405,8 +405,8 @@ __device__ __forceinline__ void stage_half_fast(const char* __restrict__ base, c
     for (int j = 0; j < 2; ++j) glds16(reinterpret_cast<const bf16_t*>(base + off[j]), lds_half + (j * 8 + wave) * 512);
 }
 
-// one staging call of the persistent kernel.  FAST (M % 128 == 0 and N % 128 == 0: every half-tile is full) compiles the clamp
-// path out; otherwise the fast path is taken per half-tile when rows [row0, row0 + 128) all exist
+// one staging call of the persistent kernel.  FAST (M % 256 == 0 and N % 256 == 0: every tile is full) compiles the clamp
+// path (and the guarded epilogue) out; otherwise the fast path is taken per half-tile when rows [row0, row0 + 128) all exist
 template <bool FAST>
 __device__ __forceinline__ void stage_half_any(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0,
                                                const uint32_t (&off)[2], bf16_t* lds_half, int wave, int lane) {
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         cursor_next(cb, w);
         // ---------------- end of an output tile: epilogue (later steps' loads keep flying)
         if (last_k) {
-            if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            if (FAST || interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
 #pragma unroll
             for (int a = 0; a < 8; ++a)
@@ -1283,7 +1283,7 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
         int grid = num_cus() & ~7;
         if (grid < 8) grid = 8;
         const dim3 g(grid), block(512);
-        const bool fast = !(p.M & 127) && !(p.N & 127);       // every half-tile full: the row-clamp staging path is compiled out
+        const bool fast = !(p.M & 255) && !(p.N & 255);       // every tile full: the clamped staging and the guarded epilogue are compiled out
         if (out_dtype == CHB_OUT_F32) {
             if (fast) hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_F32, true>), g, block, 0, s, p);
             else hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_F32, false>), g, block, 0, s, p);
