@@ -90,8 +90,23 @@ class KernelTimer:
             a[0] += 1
             a[1] += ms
             a[2] += work
-        return {k: {"launches": v[0], "total_ms": v[1], "avg_us": 1e3 * v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
-                for k, v in agg.items()}
+        return {k: {"launches": v[0], "total_ms": v[1], "avg_us": 1e3 * v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12,
+                    "work": v[2]} for k, v in agg.items()}
+
+    @staticmethod
+    def families(ks):
+        """Template instantiations of one kernel (gemm_nt256_kernel<EPI, OUT>) belong to one family: the dominant kernel of
+        the step is chosen among families, never among the instantiations of one of them."""
+        fam = {}
+        for k, v in ks.items():
+            f = fam.setdefault(k.split("<")[0], {"launches": 0, "total_ms": 0.0, "work": 0.0})
+            f["launches"] += v["launches"]
+            f["total_ms"] += v["total_ms"]
+            f["work"] += v["work"]
+        for f in fam.values():
+            f["avg_us"] = 1e3 * f["total_ms"] / f["launches"]
+            f["tflops"] = f["work"] / (f["total_ms"] * 1e-3) / 1e12
+        return fam
 
 
 def draw_randaugment_decisions(gen, n_transforms, batch, h, w):
@@ -100,28 +115,63 @@ def draw_randaugment_decisions(gen, n_transforms, batch, h, w):
             for _ in range(n_transforms)]
 
 
-def cpu_baseline(cfg_kwargs, sample_images=8, steps=2):
-    """Oracle (CPU restatement of the TF2 reference) on the same workload shape: RandAugment(2,9) + normalise +
-    ViT-B/16 forward + CE + backward + AdamW, fp32 torch-CPU, bounded to a few images."""
-    threads = max(1, min(16, os.cpu_count() or 1))      # the GPU box gives one GPU's share of host cores (16)
-    torch.set_num_threads(threads)
+def _median_time(fn, warmup, runs):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def cpu_baseline(cfg_kwargs, train_batch=32, runs=5, warmup=2):
+    """SURVEY 8(d) / BASELINE.md 4 protocol, on this host: the oracle (fp32 torch-CPU / NumPy restatement of the TF2 reference,
+    kind "port") timed as the median of `runs` runs after `warmup` warm-ups, at k = all host cores this process may use and k = 1:
+      * the metric's workload: RandAugment(2, 9) + normalise + ViT-B/16 forward + CE + backward + AdamW on B = 32 images
+        (decisions from seed 42, dropout 0.1) at k = all cores -> images/s (`value`);
+      * config 1 (ViT-Ti/16 forward, uint8[8,224,224,3] -> logits) at k = 1 and k = all cores."""
     from chambers_amd.engine import ViTConfig, init_keras_weights
     from oracle import augment_ref as A
     from oracle import rng_ref, vit_ref
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    g = np.random.Generator(np.random.PCG64(0))
+
+    # ---- config 1: ViT-Ti/16 forward, batch 8
+    ti = ViTConfig(**dict(MODELS["vitti16"], dropout_rate=0.1, image_size=(224, 224), classes=1000))
+    ti_w = {k: torch.tensor(v, dtype=torch.float32) for k, v in init_keras_weights(ti, seed=1234).items()}
+    ti_images = g.integers(0, 256, size=(8, 224, 224, 3), dtype=np.uint8)
+
+    def ti_forward():
+        with torch.no_grad():
+            vit_ref.vit_forward(ti_w, torch.from_numpy(A.imagenet_normalize(ti_images, "tf")), ti.as_oracle_cfg(), keys=None)
+
+    cfg1 = {}
+    for k in (1, cores):
+        torch.set_num_threads(k)
+        t = _median_time(ti_forward, warmup, runs)
+        cfg1["k%d" % k] = {"threads": k, "images_per_sec": 8 / t, "ms": 1e3 * t}
+
+    # ---- the metric's workload on the CPU: ViT-B/16 train step, B = 32, all cores
+    torch.set_num_threads(cores)
     cfg = ViTConfig(**cfg_kwargs)
     kw = init_keras_weights(cfg, seed=1234)
     p = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in kw.items()}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v_ = {k: torch.zeros_like(v) for k, v in p.items()}
-    g = np.random.Generator(np.random.PCG64(0))
     gd = np.random.Generator(np.random.PCG64(42))
-    images = g.integers(0, 256, size=(sample_images,) + cfg.image_size + (3,), dtype=np.uint8)
-    labels = torch.as_tensor(g.integers(0, cfg.classes, size=(sample_images,)))
+    images = g.integers(0, 256, size=(train_batch,) + cfg.image_size + (3,), dtype=np.uint8)
+    labels = torch.as_tensor(g.integers(0, cfg.classes, size=(train_batch,)))
     n_sites = 1 + 3 * cfg.n_encoder_layers
-    times = []
-    for step in range(steps + 1):
-        t0 = time.perf_counter()
-        dec = draw_randaugment_decisions(gd, 2, sample_images, *cfg.image_size)
+    state = {"step": 0}
+
+    def train_step():
+        step = state["step"]
+        dec = draw_randaugment_decisions(gd, 2, train_batch, *cfg.image_size)
         xa = A.rand_augment(images, 2, 9, dec)
         x = torch.from_numpy(A.imagenet_normalize(xa, "tf"))
         keys = {s: rng_ref.site_key(0, step, s) for s in range(n_sites)}
@@ -129,11 +179,16 @@ def cpu_baseline(cfg_kwargs, sample_images=8, steps=2):
         loss = vit_ref.sparse_ce_from_logits(logits, labels)
         grads = torch.autograd.grad(loss, list(p.values()))
         with torch.no_grad():
-            vit_ref.adamw_step({k: v.data for k, v in p.items()}, dict(zip(p.keys(), grads)), m, v_, step + 1, weight_decay=0.01)
-        times.append(time.perf_counter() - t0)
-    best = float(np.median(times[1:]))
-    return {"value": sample_images / best, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d images x %d timed steps (1 warm-up) of the same train step, fp32 torch-CPU oracle" % (sample_images, steps)}
+            vit_ref.adamw_step({k: v.data for k, v in p.items()}, dict(zip(p.keys(), grads)), m, v_, step + 1, weight_decay=0.05)
+        state["step"] = step + 1
+
+    t = _median_time(train_step, warmup, runs)
+    return {"value": train_batch / t, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "CPU restatement of the TF2 reference (oracle/, fp32 torch-CPU + NumPy): the same train step (RandAugment(2,9) + "
+                      "normalise + forward + CE + backward + AdamW) on B=%d images, median of %d runs after %d warm-ups, %d threads"
+                      % (train_batch, runs, warmup, cores),
+            "ms_per_step": 1e3 * t,
+            "config1_vitti16_forward_b8": cfg1}
 
 
 def pmc_traffic(kernel):
@@ -148,8 +203,7 @@ def pmc_traffic(kernel):
     # the live timer groups a kernel's template instantiations that are picked per call (gemm_tn256_kernel<COLSUM, FAST>: with /
     # without the ride-along bias gradient; trailing FAST = staging without clamps, gemm_nt256_kernel<EPI, OUT, FAST>); rocprofv3
     # lists them separately: launch-weighted mean over them
-    rows = [v for k, v in table.items()
-            if k == kernel or k.startswith(kernel + "<") or (kernel.endswith(">") and k.startswith(kernel[:-1] + ","))]
+    rows = [v for k, v in table.items() if k.split("<")[0] == kernel.split("<")[0]]
     n = sum(v["launches_sampled"] for v in rows)
     if not rows or not n:
         return None
@@ -216,7 +270,7 @@ def main():
 
     cfg_kwargs = dict(MODELS[args.model], dropout_rate=0.1, image_size=(args.image_size, args.image_size), classes=1000)
     cfg = ViTConfig(**cfg_kwargs)
-    eng = ViTEngine(cfg, args.batch, training=True, seed=0)
+    eng = ViTEngine(cfg, args.batch, training=True, seed=rank)      # dropout masks differ per rank, like the data
     eng.load_keras_weights(init_keras_weights(cfg, seed=1234))      # same init on every rank
     g = np.random.Generator(np.random.PCG64(rank))                  # synthetic data: seed = rank
     images = torch.as_tensor(g.integers(0, 256, size=(args.batch, args.image_size, args.image_size, 3), dtype=np.uint8), device="cuda")
@@ -262,7 +316,8 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.batch * args.steps / elapsed
         ks = timer.summary()
-        dom = max(ks, key=lambda k: ks[k]["total_ms"])
+        fams = KernelTimer.families(ks)
+        dom = max(fams, key=lambda k: fams[k]["total_ms"])
         train_flops = 3.0 * forward_flops_per_image(cfg) * args.batch
         out = {
             "metric": "images/sec ViT-B/16 224^2 train step (synthetic)" if args.model == "vitb16" and args.image_size == 224
@@ -275,9 +330,14 @@ def main():
                           "AutoAugment(policy v0)" if args.augment == "autoaugment" else "RandAugment(n=2,m=9)",
                           " OFF" if args.no_augment else "", world),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ks[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ks[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_us": ks[dom]["avg_us"], "launches": ks[dom]["launches"]},
+            # dominant kernel FAMILY (all template instantiations together): achieved = sum of 2*M*N*K over its launches / sum of
+            # their durations (HIP events on the launch stream, inside the timed region)
+            "roofline": {"bound": "mfma", "kernel": dom + "<*>", "achieved": fams[dom]["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": fams[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_us": fams[dom]["avg_us"], "launches": fams[dom]["launches"],
+                         "algorithmic_flop_per_launch": fams[dom]["work"] / fams[dom]["launches"],
+                         "families": {k: {"total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 1), "launches": v["launches"],
+                                          "frac": round(v["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)} for k, v in fams.items()}},
             "step_tflops": train_flops / (ms_per_step * 1e-3) / 1e12,
             "step_frac_of_mfma_peak": train_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "kernels": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 1), "launches": v["launches"],

@@ -17,6 +17,8 @@ c_void_p, c_int, c_int64, c_float, c_uint32 = ctypes.c_void_p, ctypes.c_int, cty
 CHB_OK, CHB_EINVAL, CHB_ELAUNCH, CHB_EUNSUPPORTED = 0, -1, -2, -3
 
 PW_INVERT, PW_POSTERIZE, PW_SOLARIZE, PW_SOLARIZE_ADD, PW_BRIGHTNESS, PW_CONTRAST, PW_COLOR = range(7)
+(AUG_IDENTITY, AUG_AUTOCONTRAST, AUG_EQUALIZE, AUG_INVERT, AUG_POSTERIZE, AUG_SOLARIZE, AUG_SOLARIZE_ADD, AUG_BRIGHTNESS, AUG_CONTRAST,
+ AUG_COLOR, AUG_SHARPNESS, AUG_AFFINE, AUG_CUTOUT) = range(13)
 NORM_CAFFE, NORM_TF, NORM_TORCH = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_PATCH = range(5)
 OUT_BF16, OUT_F32 = 0, 1
@@ -30,6 +32,7 @@ PROTOTYPES = {
     "chb_aug_autocontrast": [P, P, c_int, c_int, c_int, c_int, P, P],
     "chb_aug_equalize": [P, P, c_int, c_int, c_int, c_int, P, P],
     "chb_aug_sharpness": [P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "chb_aug_dispatch": [P, P, c_int, c_int, c_int, P, c_int, P, P],
     "chb_normalize_u8": [P, P, c_int64, c_int, c_int, P],
     "chb_normalize_f32": [P, P, c_int64, c_int, c_int, P],
     "chb_normalize_patchify_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, P],
@@ -41,7 +44,7 @@ PROTOTYPES = {
     "chb_gemm_tn_ws": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P, c_int64, c_int, P, P],
     "chb_gemm_tn_fold": [P, c_int64, P, c_int64, c_int, c_int, c_int, P],
     "chb_layernorm_fwd": [P, c_int64, P, P, P, P, P, c_int, c_int, c_float, P],
-    "chb_layernorm_bwd": [P, P, c_int64, P, P, P, P, c_int64, c_int, P, P, c_int, c_int, P, P, c_float, c_uint32, P],
+    "chb_layernorm_bwd": [P, P, c_int64, P, P, P, P, c_int64, c_int, P, P, c_int, c_int, P, P, c_float, c_uint32, c_int, P],
     "chb_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P],
     "chb_attention_bwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P],
     "chb_cls_row": [P, P, P, c_int, c_int, c_int, c_float, c_uint32, P],
@@ -63,7 +66,9 @@ PROTOTYPES = {
     "chb_tanh_fwd": [P, P, c_int64, P],
     "chb_tanh_bwd": [P, P, P, c_int64, P],
     "chb_cast_transpose": [P, P, P, P, c_int, c_int, P],
-    "chb_adamw": [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P],
+    "chb_adamw": [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_int, P],
+    "chb_zero_f32": [P, c_int64, P],
+    "chb_set_option": [ctypes.c_char_p, c_int],
 }
 INFO_SYMBOLS = ["chb_version", "chb_build_arch"]
 
@@ -129,6 +134,11 @@ def require_gpu(*tensors):
         if t is not None and not t.is_cuda:
             raise ChambersHipError(
                 "chambers_amd kernels run on an MI355X only; got a %s tensor (no CPU fallback)" % t.device)
+
+
+def set_option(name, value):
+    """A/B switch of the library (see chb_set_option in include/chambers_hip.h); name without the CHB_ prefix."""
+    call("chb_set_option", name.encode(), int(value))
 
 
 def call(name, *args):

@@ -6,6 +6,7 @@ The reference selects ops with n*K `tf.cond`s over TF's global RNG; here the sel
 the host (explicit `decisions`, or drawn from `chambers_amd.rng`) and only the chosen op's HIP
 kernel is launched.
 """
+import numpy as np
 import torch
 
 from .. import rng
@@ -163,12 +164,27 @@ class AutoAugment(Layer):
         if not _is_training(training):
             return inputs
         if self.elementwise:
-            outs = []
-            for n in range(inputs.shape[0]):
-                d = decision[n] if decision is not None else self.draw_decision()
-                outs.append(self._apply(inputs[n:n + 1], d))
-            return torch.cat(outs, dim=0) if outs else inputs
+            return self._elementwise(inputs, decision)
         return self._apply(inputs, decision if decision is not None else self.draw_decision())
+
+    def _elementwise(self, inputs, decisions):
+        """elementwise=True (:135, RandomChoice :563-570): every image draws its own sub-policy, its two chance draws and its
+        sign draws.  The two steps of the 25 sub-policies are two launches of the per-image dispatch kernel."""
+        from .. import kernels as K
+        b = inputs.shape[0]
+        if b == 0:
+            return inputs
+        h, w = int(inputs.shape[1]), int(inputs.shape[2])
+        items = np.zeros((2, b), dtype=K.AUG_ITEM_DTYPE)
+        for n in range(b):
+            d = decisions[n] if decisions is not None else self.draw_decision()
+            seq = self.transforms[int(d["policy"])]
+            for j, chance in enumerate(seq.layers):
+                items[j, n] = chance.dispatch_item(h, w, apply=bool(d["apply"][j]), negate=bool(d["negate"][j]))
+        x = inputs
+        for j in range(2):
+            x = K.aug_dispatch(x, items[j])
+        return x
 
     def compute_output_shape(self, input_shape):
         return self._transform.compute_output_shape(input_shape)

@@ -14,6 +14,7 @@ import math
 import numpy as np
 import torch
 
+from .. import _lib
 from .. import kernels as K
 from .. import rng
 from .._keras_like import InputSpec, Layer, deserialize, register_keras_serializable, serialize
@@ -43,6 +44,9 @@ class AutoContrast(Layer):
     def call(self, inputs, **kwargs):
         return K.aug_autocontrast(inputs)
 
+    def dispatch_item(self, height, width, **kwargs):
+        return K.aug_item(_lib.AUG_AUTOCONTRAST)
+
 
 @register_keras_serializable(package="Chambers")
 class Equalize(Layer):
@@ -55,6 +59,9 @@ class Equalize(Layer):
     def call(self, inputs, **kwargs):
         return K.aug_equalize(inputs)
 
+    def dispatch_item(self, height, width, **kwargs):
+        return K.aug_item(_lib.AUG_EQUALIZE)
+
 
 @register_keras_serializable(package="Chambers")
 class Invert(Layer):
@@ -66,6 +73,9 @@ class Invert(Layer):
 
     def call(self, inputs, **kwargs):
         return K.aug_pointwise(inputs, K.PW_INVERT)
+
+    def dispatch_item(self, height, width, **kwargs):
+        return K.aug_item(_lib.AUG_INVERT)
 
 
 class _Warp(Layer):
@@ -83,6 +93,12 @@ class _Warp(Layer):
             raise ValueError("the MI355X warp kernel implements interpolation='nearest', fill_mode='constant' "
                              "(the only combination the augmentation schemes use, augmentation_schemes.py:7-9)")
         return K.aug_affine(inputs, transform, fill=int(self.fill_value))
+
+    def _item(self, transform):
+        if self.interpolation != "nearest" or self.fill_mode != "constant":
+            raise ValueError("the MI355X warp kernel implements interpolation='nearest', fill_mode='constant'")
+        t = np.asarray(transform, dtype=np.float32)
+        return K.aug_item(_lib.AUG_AFFINE, i=(int(self.fill_value),), f=t[:6])
 
     def _warp_cfg(self):
         return {"interpolation": self.interpolation, "fill_mode": self.fill_mode, "fill_value": self.fill_value}
@@ -111,6 +127,9 @@ class Rotate(_Warp):
         radians = _randomly_negate_value(self._radians, negate)
         return self._warp(inputs, self.transform_for(radians, inputs.shape[1], inputs.shape[2]))
 
+    def dispatch_item(self, height, width, negate=None, **kwargs):
+        return self._item(self.transform_for(_randomly_negate_value(self._radians, negate), height, width))
+
     def get_config(self):
         return _base_cfg(self, dict({"degrees": self.degrees}, **self._warp_cfg()))
 
@@ -129,6 +148,9 @@ class Posterize(Layer):
         # TF's shift functors clamp the count to bit-width-1 (reached by AutoAugment sub-policy 22)
         return K.aug_pointwise(inputs, K.PW_POSTERIZE, i0=min(max(int(self._shift), 0), 7))
 
+    def dispatch_item(self, height, width, **kwargs):
+        return K.aug_item(_lib.AUG_POSTERIZE, i=(min(max(int(self._shift), 0), 7),))
+
     def get_config(self):
         return _base_cfg(self, {"bits": self.bits})
 
@@ -144,6 +166,9 @@ class Solarize(Layer):
 
     def call(self, inputs, **kwargs):
         return K.aug_pointwise(inputs, K.PW_SOLARIZE, i0=int(self.threshold))
+
+    def dispatch_item(self, height, width, **kwargs):
+        return K.aug_item(_lib.AUG_SOLARIZE, i=(int(self.threshold),))
 
     def get_config(self):
         return _base_cfg(self, {"threshold": self.threshold})
@@ -161,6 +186,9 @@ class SolarizeAdd(Layer):
 
     def call(self, inputs, **kwargs):
         return K.aug_pointwise(inputs, K.PW_SOLARIZE_ADD, i0=int(self.threshold), i1=int(self.addition))
+
+    def dispatch_item(self, height, width, **kwargs):
+        return K.aug_item(_lib.AUG_SOLARIZE_ADD, i=(int(self.threshold), int(self.addition)))
 
     def get_config(self):
         return _base_cfg(self, {"addition": self.addition, "threshold": self.threshold})
@@ -184,6 +212,9 @@ class Color(Layer):
         if self.factor == 1.0:
             return inputs.clone()
         return K.aug_pointwise(inputs, K.PW_COLOR, factor=self.factor)
+
+    def dispatch_item(self, height, width, **kwargs):
+        return K.aug_item(_lib.AUG_COLOR, f=(self.factor,))     # blend()'s factor 0 / 1 short-cuts are what the arithmetic gives
 
     def get_config(self):
         return _base_cfg(self, {"factor": self.factor})
@@ -212,6 +243,10 @@ class Contrast(Layer):
             return torch.full_like(inputs, const)
         return K.aug_pointwise(inputs, K.PW_CONTRAST, factor=self.factor, i0=const)
 
+    def dispatch_item(self, height, width, **kwargs):
+        # per image = a batch-1 tensor: the "mean" is H*W/256 (196 for 224x224, clipped to 255 from 256x256 on)
+        return K.aug_item(_lib.AUG_CONTRAST, i=(self.degenerate_constant(height * width),), f=(self.factor,))
+
     def get_config(self):
         return _base_cfg(self, {"factor": self.factor})
 
@@ -232,6 +267,9 @@ class Brightness(Layer):
             return torch.zeros_like(inputs)
         return K.aug_pointwise(inputs, K.PW_BRIGHTNESS, factor=self.factor)
 
+    def dispatch_item(self, height, width, **kwargs):
+        return K.aug_item(_lib.AUG_BRIGHTNESS, f=(self.factor,))
+
     def get_config(self):
         return _base_cfg(self, {"factor": self.factor})
 
@@ -250,6 +288,11 @@ class Sharpness(Layer):
             return inputs.clone()
         return K.aug_sharpness(inputs, self.factor)
 
+    def dispatch_item(self, height, width, **kwargs):
+        if self.factor == 1.0:
+            return K.aug_item(_lib.AUG_IDENTITY)
+        return K.aug_item(_lib.AUG_SHARPNESS, f=(self.factor,))
+
     def get_config(self):
         return _base_cfg(self, {"factor": self.factor})
 
@@ -266,6 +309,9 @@ class ShearX(_Warp):
         level = _randomly_negate_value(self.level, negate)
         return self._warp(inputs, [1.0, level, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
 
+    def dispatch_item(self, height, width, negate=None, **kwargs):
+        return self._item([1.0, _randomly_negate_value(self.level, negate), 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+
     def get_config(self):
         return _base_cfg(self, dict({"level": self.level}, **self._warp_cfg()))
 
@@ -281,6 +327,9 @@ class ShearY(_Warp):
     def call(self, inputs, negate=None, **kwargs):
         level = _randomly_negate_value(self.level, negate)
         return self._warp(inputs, [1.0, 0.0, 0.0, level, 1.0, 0.0, 0.0, 0.0])
+
+    def dispatch_item(self, height, width, negate=None, **kwargs):
+        return self._item([1.0, 0.0, 0.0, _randomly_negate_value(self.level, negate), 1.0, 0.0, 0.0, 0.0])
 
     def get_config(self):
         return _base_cfg(self, dict({"level": self.level}, **self._warp_cfg()))
@@ -299,6 +348,10 @@ class TranslateX(_Warp):
         dx = -pixels
         return self._warp(inputs, [1.0, 0.0, -dx, 0.0, 1.0, -0.0, 0.0, 0.0])
 
+    def dispatch_item(self, height, width, negate=None, **kwargs):
+        dx = -_randomly_negate_value(self.pixels, negate)
+        return self._item([1.0, 0.0, -dx, 0.0, 1.0, -0.0, 0.0, 0.0])
+
     def get_config(self):
         return _base_cfg(self, dict({"pixels": self.pixels}, **self._warp_cfg()))
 
@@ -315,6 +368,10 @@ class TranslateY(_Warp):
         pixels = _randomly_negate_value(self.pixels, negate)
         dy = -pixels
         return self._warp(inputs, [1.0, 0.0, -0.0, 0.0, 1.0, -dy, 0.0, 0.0])
+
+    def dispatch_item(self, height, width, negate=None, **kwargs):
+        dy = -_randomly_negate_value(self.pixels, negate)
+        return self._item([1.0, 0.0, -0.0, 0.0, 1.0, -dy, 0.0, 0.0])
 
     def get_config(self):
         return _base_cfg(self, dict({"pixels": self.pixels}, **self._warp_cfg()))
@@ -336,6 +393,16 @@ class CutOut(Layer):
             g = rng.host_generator()
             centers = np.stack([g.integers(0, h, size=b), g.integers(0, w, size=b)], axis=1).astype(np.int32)
         return K.aug_cutout(inputs, centers, self.mask_size, self.constant_values)
+
+    def dispatch_item(self, height, width, centers=None, **kwargs):
+        if int(self.mask_size) % 2 != 0:
+            raise ValueError("mask_size should be divisible by 2")
+        if centers is None:
+            g = rng.host_generator()
+            cy, cx = int(g.integers(0, height)), int(g.integers(0, width))
+        else:
+            cy, cx = (int(v) for v in np.asarray(centers).reshape(-1)[:2])
+        return K.aug_item(_lib.AUG_CUTOUT, i=(cy, cx, int(self.mask_size) // 2, int(self.constant_values) & 0xff))
 
     def get_config(self):
         return _base_cfg(self, {"mask_size": self.mask_size, "constant_values": self.constant_values})
@@ -362,6 +429,11 @@ class RandomChance(Layer):
         if apply is None:
             apply = bool(rng.host_generator().uniform() < self.probability)
         return self.transform(inputs, **kwargs) if apply else inputs
+
+    def dispatch_item(self, height, width, apply=None, **kwargs):
+        if apply is None:
+            apply = bool(rng.host_generator().uniform() < self.probability)
+        return self.transform.dispatch_item(height, width, **kwargs) if apply else K.aug_item(_lib.AUG_IDENTITY)
 
     def compute_output_shape(self, input_shape):
         return self.transform.compute_output_shape(input_shape)
@@ -393,13 +465,35 @@ class RandomChoice(Layer):
 
     def call(self, inputs, choices=None, slot_kwargs=None, **kwargs):
         if self.elementwise:
+            return self._elementwise(inputs, choices, slot_kwargs)
+        return self._random_transforms(inputs, choices, slot_kwargs)
+
+    def _elementwise(self, inputs, choices, slot_kwargs):
+        """tf.map_fn over batch-1 tensors (:565-567): every image draws its own transform index per slot, and the chosen
+        transform sees a batch of one (its sign draw, cutout centre and Contrast's constant are per image).  When every
+        transform can describe itself as a record of the per-image dispatch kernel, a slot is ONE launch for the whole batch
+        (chb_aug_dispatch); transforms that cannot (user-supplied layers) take the image-by-image route."""
+        b = inputs.shape[0]
+        if b == 0:
+            return inputs
+        if not all(hasattr(t, "dispatch_item") for t in self.transforms) or inputs.dim() != 4 or inputs.shape[-1] != 3:
             outs = []
-            for n in range(inputs.shape[0]):
+            for n in range(b):
                 ch = None if choices is None else choices[n]
                 sk = None if slot_kwargs is None else slot_kwargs[n]
                 outs.append(self._random_transforms(inputs[n:n + 1], ch, sk))
-            return torch.cat(outs, dim=0) if outs else inputs
-        return self._random_transforms(inputs, choices, slot_kwargs)
+            return K.concat_batch(outs)
+        h, w = int(inputs.shape[1]), int(inputs.shape[2])
+        items = np.zeros((self.n_transforms, b), dtype=K.AUG_ITEM_DTYPE)
+        for n in range(b):                    # draw order of the reference's map_fn body: image by image, slot by slot
+            for i in range(self.n_transforms):
+                idx = int(rng.host_generator().integers(0, len(self.transforms))) if choices is None else int(choices[n][i])
+                kw = {} if slot_kwargs is None else dict(slot_kwargs[n][i])
+                items[i, n] = self.transforms[idx].dispatch_item(h, w, **kw)
+        x = inputs
+        for i in range(self.n_transforms):
+            x = K.aug_dispatch(x, items[i])
+        return x
 
     def _random_transforms(self, inputs, choices=None, slot_kwargs=None):
         for i in range(self.n_transforms):

@@ -16,6 +16,7 @@
 // layers/attention.py:13-23 (scores / sqrt(head_dim) after the matmul), :120-125.
 #include "common.hpp"
 #include "../../include/chambers_hip.h"
+#include <atomic>
 
 namespace {
 
@@ -940,8 +941,7 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
     // Short sequences (N <= 128): K / V of the head resident in LDS, whole score row in registers.  Otherwise the streaming
     // kernel with online softmax (any N; at N = 197 it runs 4 waves per SIMD against 2 and measures ~10 % faster).
     // CHB_ATTN_FWD_ALGO = 1 | 2 forces resident (N <= 224) | streaming; the parity tests cross-check the two.
-    const char* algo_env = getenv("CHB_ATTN_FWD_ALGO");
-    const int algo = algo_env ? atoi(algo_env) : 0;
+    const int algo = chb_option(CHB_OPT_ATTN_FWD_ALGO);
     if (N > 224 || algo == 2 || (algo != 1 && N > 128)) {
         const dim3 grid2(B * H, (N + 127) / 128);
         if (thr) hipLaunchKernelGGL((attn_fwd_stream_kernel<true>), grid2, dim3(512), 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key);
@@ -977,8 +977,8 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
     hipStream_t s = (hipStream_t)stream;
     // N <= 224: one pass with the whole head resident in LDS.  Longer sequences (or CHB_ATTN_BWD_ALGO=2, used by the
     // parity tests to cross-check the two paths on the same input): dK/dV pass + dQ pass.
-    const char* algo_env = getenv("CHB_ATTN_BWD_ALGO");
-    const bool two_pass = N > 224 || (algo_env && atoi(algo_env) == 2);
+    const int bwd_algo = chb_option(CHB_OPT_ATTN_BWD_ALGO);
+    const bool two_pass = N > 224 || bwd_algo == 2;
     if (two_pass) {
         const dim3 grid2(B * H, (N + 127) / 128);
         const bf16_t* a0 = (const bf16_t*)qkv;
@@ -1001,9 +1001,13 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
 #define CHB_BWD_V(NTP, NW, DB)                                                                                                    \
     do {                                                                                                                         \
         const size_t lds = bwd_lds_bytes<NTP>();                                                                                 \
-        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, true, NW, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
-            hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, false, NW, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
-            return CHB_ELAUNCH;                                                                                                  \
+        static std::atomic<bool> attr_set{false};   /* once per instantiation: a driver call, not per launch (graph capture) */    \
+        if (!attr_set.load(std::memory_order_acquire)) {                                                                         \
+            if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, true, NW, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
+                hipFuncSetAttribute((const void*)attn_bwd_kernel<NTP, false, NW, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+                return CHB_ELAUNCH;                                                                                              \
+            attr_set.store(true, std::memory_order_release);                                                                     \
+        }                                                                                                                        \
         if (thr) hipLaunchKernelGGL((attn_bwd_kernel<NTP, true, NW, DB>), grid, dim3(NW * 64), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
                            lse, (bf16_t*)dqkv, N, H, scale, scale_log2, ds, thr, drop_key, db);                                  \
         else hipLaunchKernelGGL((attn_bwd_kernel<NTP, false, NW, DB>), grid, dim3(NW * 64), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o,  \
@@ -1019,7 +1023,7 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
     if (N <= 32) CHB_BWD(1, 8);
     else if (N <= 64) CHB_BWD(2, 8);
     else if (N <= 128) CHB_BWD(4, 8);
-    else if (algo_env && atoi(algo_env) == 1) CHB_BWD(7, 8);   // 8-wave variant kept for A/B timing
+    else if (bwd_algo == 1) CHB_BWD(7, 8);   // 8-wave variant kept for A/B timing
     else CHB_BWD(7, 16);
 #undef CHB_BWD_V
 #undef CHB_BWD

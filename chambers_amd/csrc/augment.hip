@@ -894,6 +894,261 @@ __global__ void __launch_bounds__(256) patchify_f32_kernel(const float* __restri
     }
 }
 
+
+// ---- per-image op dispatch (RandomChoice(elementwise=True), image_augmentations.py:563-570 + 606-617) ----------------------
+// The reference maps `_random_transforms` over the batch with tf.map_fn, every image as a batch-1 tensor: op index, sign draw,
+// cutout centre and Contrast's constant are PER IMAGE.  One slot of such a scheme is ONE launch here: blockIdx.y = image, the
+// block reads that image's 64-byte record (op id + parameters, written by the host from the explicit decisions) and branches
+// once, uniformly, into the op's body; bodies are the arithmetic of the batch kernels above, bit for bit.  The two statistics ops
+// (AutoContrast, Equalize) become a per-(image, channel) 256-entry table: a histogram pass over the images that chose them, a
+// table-building pass (AutoContrast's table is its own fp32 expression evaluated on the 256 possible inputs), then the same
+// gather as Equalize.  RGB only (the schemes' InputSpec is uint8 NHWC and Color needs 3 channels).
+struct __attribute__((aligned(16))) AugItem {
+    int32_t op;
+    int32_t i0, i1, i2, i3;
+    int32_t pad[3];
+    float f[8];
+};
+static_assert(sizeof(AugItem) == 64, "AugItem is the 64-byte record of include/chambers_hip.h");
+
+template <bool FAST>
+__device__ __forceinline__ void load_quad(const uint8_t* __restrict__ rowp, int x0, int W, uint8_t (&b)[12]) {
+    if (FAST) {
+        unpack12(*reinterpret_cast<const px4_t*>(rowp + (int64_t)x0 * 3), b);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b[i] = (x0 + i / 3 < W) ? rowp[(int64_t)x0 * 3 + i] : (uint8_t)0;
+    }
+}
+template <bool FAST>
+__device__ __forceinline__ void store_quad(uint8_t* __restrict__ rowp, int x0, int W, const uint8_t (&b)[12]) {
+    if (FAST) {
+        *reinterpret_cast<px4_t*>(rowp + (int64_t)x0 * 3) = pack12(b);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            if (x0 + i / 3 < W) rowp[(int64_t)x0 * 3 + i] = b[i];
+    }
+}
+
+// histogram of the images whose slot op is AutoContrast or Equalize; grid = (slices, B)
+__global__ void __launch_bounds__(256) hist_sel_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ ws, int HW,
+                                                       const AugItem* __restrict__ items) {
+    const int n = blockIdx.y;
+    const int op = items[n].op;
+    if (op != CHB_AUG_AUTOCONTRAST && op != CHB_AUG_EQUALIZE) return;   // uniform per block
+    __shared__ int32_t h[3 * 256];
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const uint8_t* img = in + (int64_t)n * HW * 3;
+    const int64_t nbytes = (int64_t)HW * 3;
+    const bool aligned = (((uintptr_t)img) & 3) == 0;
+    const int64_t ng = aligned ? nbytes / 12 : 0;
+    const px4_t* p4 = reinterpret_cast<const px4_t*>(img);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t b[12];
+        unpack12(p4[g], b);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) atomicAdd(&h[(i % 3) * 256 + b[i]], 1);
+    }
+    for (int64_t i = ng * 12 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[(int)(i % 3) * 256 + img[i]], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += blockDim.x)
+        if (h[i]) atomicAdd(&ws[(int64_t)n * 768 + i], h[i]);
+}
+
+// histogram -> table, in place; grid = B * 3 blocks (image, channel), thread = input value
+__global__ void __launch_bounds__(256) lut_build_kernel(int32_t* __restrict__ ws, const AugItem* __restrict__ items) {
+    const int n = blockIdx.x / 3;
+    const int op = items[n].op;
+    if (op != CHB_AUG_AUTOCONTRAST && op != CHB_AUG_EQUALIZE) return;
+    __shared__ int32_t s[256];
+    __shared__ int32_t first_nz, last_nz;
+    int32_t* h = ws + (int64_t)blockIdx.x * 256;
+    const int t = threadIdx.x;
+    const int32_t mine = h[t];
+    s[t] = mine;
+    if (t == 0) { first_nz = 255; last_nz = 0; }
+    __syncthreads();
+    if (mine != 0) { atomicMax(&last_nz, t); atomicMin(&first_nz, t); }
+    __syncthreads();
+    int32_t lut = t;
+    if (op == CHB_AUG_AUTOCONTRAST) {   // :72-86 evaluated on the value t (same fp32 sequence as autocontrast_apply_kernel)
+        const float lo = (float)first_nz, hi = (float)last_nz;
+        const float rng = hi - lo;
+        float sc = (rng != 0.0f) ? 255.0f / rng : 0.0f;
+        float of = (-lo) * sc;
+        const float mask = hi > lo ? 1.0f : 0.0f;
+        sc = sc * mask + (1.0f - mask);
+        of = of * mask;
+        float v = (float)t * sc;
+        v = v + of;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        lut = (int32_t)trunc_u8(v);
+    } else {                            // tfa.image.equalize (as equalize_lut_kernel)
+        for (int o = 1; o < 256; o <<= 1) {
+            const int32_t v = (t >= o) ? s[t - o] : 0;
+            __syncthreads();
+            s[t] += v;
+            __syncthreads();
+        }
+        const int32_t total = s[255];
+        const int32_t excl = s[t] - mine;
+        const int32_t step = (total - h[last_nz]) / 255;
+        __syncthreads();
+        if (step != 0) {
+            lut = (excl + step / 2) / step;
+            lut = lut < 0 ? 0 : (lut > 255 ? 255 : lut);
+        }
+    }
+    h[t] = lut;
+}
+
+__device__ __forceinline__ uint8_t blend_rt(uint8_t deg, uint8_t x, float factor, bool clip) {
+    return clip ? blend1<true>(deg, x, factor) : blend1<false>(deg, x, factor);
+}
+
+// grid = (row groups of 16, B); wave = 4 consecutive rows, lane = 4-pixel quad
+template <bool FAST>
+__global__ void __launch_bounds__(256) aug_dispatch_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H, int W,
+                                                           const AugItem* __restrict__ items, const int32_t* __restrict__ ws) {
+    __shared__ uint8_t lut[768];
+    const int n = blockIdx.y;
+    const AugItem it = items[n];
+    const int op = it.op;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t row_bytes = (int64_t)W * 3;
+    const int64_t img_bytes = (int64_t)H * row_bytes;
+    const uint8_t* img = in + (int64_t)n * img_bytes;
+    uint8_t* oimg = out + (int64_t)n * img_bytes;
+    const int wq = (W + 3) >> 2;
+    const int row0 = blockIdx.x * 16 + wave * 4;
+    if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
+        for (int i = threadIdx.x; i < 768; i += blockDim.x) lut[i] = (uint8_t)ws[(int64_t)n * 768 + i];
+        __syncthreads();
+    }
+    if (row0 >= H) return;
+    const float factor = it.f[0];
+    const bool clip = !(factor > 0.0f && factor < 1.0f);
+    PwParams pp{0, factor, it.i0, it.i1};
+
+    if (op == CHB_AUG_AFFINE) {   // tfa.image.transform, nearest, constant fill; projective row of every scheme op is 0
+        const float a0 = it.f[0], a1 = it.f[1], a2 = it.f[2], b0 = it.f[3], b1 = it.f[4], b2 = it.f[5];
+        const uint32_t fillw = ((uint32_t)(it.i0 & 0xff)) * 0x01010101u;
+        const float fW = (float)W, fH = (float)H;
+        for (int xq = lane; xq < wq; xq += 64) {
+            const int x0 = xq * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = row0 + k;
+                if (y >= H) break;
+                const float fy = (float)y;
+                const float ay = a1 * fy, by = b1 * fy;
+                uint8_t b[12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float fx = (float)(x0 + i);
+                    const float ix = (a0 * fx + ay) + a2;
+                    const float iy = (b0 * fx + by) + b2;
+                    const float rx = roundf(ix), ry = roundf(iy);   // half away from zero
+                    const bool ok = (rx >= 0.0f) && (rx < fW) && (ry >= 0.0f) && (ry < fH);
+                    const int64_t off = ok ? ((int64_t)(int)ry * W + (int)rx) * 3 : 0;
+                    uint32_t v;
+                    if (FAST) {   // one unaligned dword; the last pixel of the image steps back a byte instead of reading past it
+                        const int over = (off + 4 > img_bytes) ? 1 : 0;
+                        v = reinterpret_cast<const u32_unaligned*>(img + off - over)->v >> (8 * over);
+                    } else {
+                        v = (uint32_t)img[off] | ((uint32_t)img[off + 1] << 8) | ((uint32_t)img[off + 2] << 16);
+                    }
+                    v = ok ? v : fillw;
+                    b[3 * i + 0] = v & 0xff; b[3 * i + 1] = (v >> 8) & 0xff; b[3 * i + 2] = (v >> 16) & 0xff;
+                }
+                store_quad<FAST>(oimg + (int64_t)y * row_bytes, x0, W, b);
+            }
+        }
+        return;
+    }
+    if (op == CHB_AUG_SHARPNESS) {   // tfa.image.sharpness: 3x3 [[1,1,1],[1,5,1],[1,1,1]]/13 on the interior, row-major fp32 sum
+        const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+        const int mode = factor == 0.0f ? 0 : (clip ? 2 : 1);
+        for (int xq = lane; xq < wq; xq += 64) {
+            const int x0 = xq * 4;
+            for (int k = 0; k < 4; ++k) {
+                const int y = row0 + k;
+                if (y >= H) break;
+                const bool yin = (y >= 1) && (y < H - 1);
+                uint8_t b[12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int x = x0 + i;
+                    const bool live = x < W;
+                    const bool interior = live && yin && (x >= 1) && (x < W - 1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint8_t orig = live ? img[((int64_t)y * W + x) * 3 + c] : (uint8_t)0;
+                        uint8_t deg = orig;
+                        if (interior) {
+                            float acc = 0.0f;
+#pragma unroll
+                            for (int ky = -1; ky <= 1; ++ky)
+#pragma unroll
+                                for (int kx = -1; kx <= 1; ++kx) {
+                                    const float v = (float)img[((int64_t)(y + ky) * W + (x + kx)) * 3 + c];
+                                    acc = acc + v * ((ky == 0 && kx == 0) ? k5 : k1);
+                                }
+                            deg = trunc_u8(acc);
+                        }
+                        b[3 * i + c] = mode == 0 ? deg : blend_rt(deg, orig, factor, mode == 2);
+                    }
+                }
+                store_quad<FAST>(oimg + (int64_t)y * row_bytes, x0, W, b);
+            }
+        }
+        return;
+    }
+    // row-local ops: load 4 rows, transform, store
+    for (int xq = lane; xq < wq; xq += 64) {
+        const int x0 = xq * 4;
+        uint8_t b[4][12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (row0 + k < H) load_quad<FAST>(img + (int64_t)(row0 + k) * row_bytes, x0, W, b[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = row0 + k;
+            if (y >= H) break;
+            switch (op) {   // uniform
+                case CHB_AUG_AUTOCONTRAST:
+                case CHB_AUG_EQUALIZE:
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) b[k][i] = lut[(i % 3) * 256 + b[k][i]];
+                    break;
+                case CHB_AUG_INVERT: pointwise12<CHB_PW_INVERT>(b[k], pp); break;
+                case CHB_AUG_POSTERIZE: pointwise12<CHB_PW_POSTERIZE>(b[k], pp); break;
+                case CHB_AUG_SOLARIZE: pointwise12<CHB_PW_SOLARIZE>(b[k], pp); break;
+                case CHB_AUG_SOLARIZE_ADD: pointwise12<CHB_PW_SOLARIZE_ADD>(b[k], pp); break;
+                case CHB_AUG_BRIGHTNESS: pointwise12<CHB_PW_BRIGHTNESS>(b[k], pp); break;
+                case CHB_AUG_CONTRAST: pointwise12<CHB_PW_CONTRAST>(b[k], pp); break;
+                case CHB_AUG_COLOR: pointwise12<CHB_PW_COLOR>(b[k], pp); break;
+                case CHB_AUG_CUTOUT: {   // i0 = cy, i1 = cx, i2 = half, i3 = value
+                    const int xa = max(0, it.i1 - it.i2), xb = min(W, it.i1 + it.i2);
+                    const bool rowin = (y >= max(0, it.i0 - it.i2)) && (y < min(H, it.i0 + it.i2));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool inside = rowin && (x0 + i >= xa) && (x0 + i < xb);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) b[k][3 * i + c] = inside ? (uint8_t)it.i3 : b[k][3 * i + c];
+                    }
+                    break;
+                }
+                default: break;   // CHB_AUG_IDENTITY: RandomChance not taken
+            }
+            store_quad<FAST>(oimg + (int64_t)y * row_bytes, x0, W, b[k]);
+        }
+    }
+}
+
 const NormConst kCaffe = {{103.939f, 116.779f, 123.68f}, {1.f, 1.f, 1.f}};
 const NormConst kTorch = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};
 
@@ -939,8 +1194,7 @@ int chb_aug_affine(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, 
         (int64_t)H * W * 3 < 2147483647LL) {
         // rows stay rows (shear, translate): the row-per-wave kernel; rows mix (rotation): the tiled one.  CHB_AFFINE_ALGO forces
         // 1 = rows, 2 = 32 x 8 tiles, 3 = 16 x 16 tiles (A/B timing).
-        const char* e = getenv("CHB_AFFINE_ALGO");
-        int algo = e ? atoi(e) : 0;
+        int algo = chb_option(CHB_OPT_AFFINE_ALGO);
         if (algo < 1 || algo > 3) algo = (t[3] == 0.0f) ? 1 : 3;
         if (algo == 1) {
             hipLaunchKernelGGL(affine_rgb_kernel, dim3(row_grid(((int64_t)B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W,
@@ -1007,6 +1261,29 @@ int chb_aug_equalize(const uint8_t* in, uint8_t* out, int B, int H, int W, int C
     hipLaunchKernelGGL(hist_kernel, dim3(sl, B), dim3(256), 0, s, in, workspace, H * W, C);
     hipLaunchKernelGGL(equalize_lut_kernel, dim3(B * C), dim3(256), 0, s, workspace);
     hipLaunchKernelGGL(lut_apply_kernel, dim3(sl, B), dim3(256), 0, s, in, out, workspace, H * W, C);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const void* items_dev, int n_stats, int32_t* workspace,
+                     void* stream) {
+    if (B == 0) return CHB_OK;
+    if (!in || !out || !items_dev || B < 0 || H <= 0 || W <= 0 || n_stats < 0) return CHB_EINVAL;
+    if (n_stats > 0 && !workspace) return CHB_EINVAL;
+    if ((int64_t)H * W * 3 >= 2147483647LL || B > 65535) return CHB_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const AugItem* items = (const AugItem*)items_dev;
+    if (n_stats > 0) {
+        const int nws = B * 768;
+        hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, workspace, nws, 1);
+        const int sl = slices_for((int64_t)H * W * 3, n_stats);
+        hipLaunchKernelGGL(hist_sel_kernel, dim3(sl, B), dim3(256), 0, s, in, workspace, H * W, items);
+        hipLaunchKernelGGL(lut_build_kernel, dim3(B * 3), dim3(256), 0, s, workspace, items);
+    }
+    const dim3 grid((H + 15) / 16, B);
+    const bool fast = (W & 3) == 0 && !((uintptr_t)in & 3) && !((uintptr_t)out & 3);
+    if (fast) hipLaunchKernelGGL(aug_dispatch_kernel<true>, grid, dim3(256), 0, s, in, out, B, H, W, items, workspace);
+    else hipLaunchKernelGGL(aug_dispatch_kernel<false>, grid, dim3(256), 0, s, in, out, B, H, W, items, workspace);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

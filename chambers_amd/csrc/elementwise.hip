@@ -7,8 +7,20 @@
 // AdamW (optimizers.py:147-155,372-464).
 #include "common.hpp"
 #include "../../include/chambers_hip.h"
+#include <atomic>
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
+
+struct OptionDef { const char* name; int dflt; };
+const OptionDef kOptions[CHB_OPT_COUNT] = {
+    {"ATTN_FWD_ALGO", 0}, {"ATTN_BWD_ALGO", 0}, {"AFFINE_ALGO", 0}, {"GEMM_ALGO", 0}, {"GEMM_WALK", 1}, {"TN_ATOMICS", 0}, {"TN_FAST", 1},
+    {"GEMM_EPI_OVERLAP", 1},
+};
+std::atomic<int> g_option[CHB_OPT_COUNT];
+std::atomic<bool> g_option_read[CHB_OPT_COUNT];
 
 inline int grid_for(int64_t n, int cap = 8192) {
     int64_t b = (n + 255) / 256;
@@ -145,14 +157,15 @@ __global__ void __launch_bounds__(256) softmax_ce_kernel(const float* __restrict
         for (int c = lane; c < classes; c += 64) s += expf(z[c] - mx);
         s = wave_sum(s);
         const int lab = labels[b];
-        const float lse = mx + logf(s);
-        if (lane == 0) loss[b] = lse - z[lab];
-        if (dl) {
+        const bool lab_ok = (unsigned)lab < (unsigned)classes;    // labels are validated on the device: an out-of-range label (a -1
+        const float lse = mx + logf(s);                           // "ignore" index, a corrupt value) never indexes the logits row;
+        if (lane == 0) loss[b] = lab_ok ? lse - z[lab] : NAN;     // its loss is NaN (TF's sparse CE on CPU raises, on GPU yields NaN)
+        if (dl) {                                                 // and its gradient row NaN, so the step cannot pass silently
             bf16_t* d = dl + (int64_t)b * ld_d;
             const float inv = 1.0f / s;
             for (int c = lane; c < (int)ld_d; c += 64) {
                 float g = 0.f;
-                if (c < classes) g = (expf(z[c] - mx) * inv - (c == lab ? 1.0f : 0.0f)) * grad_scale;
+                if (c < classes) g = lab_ok ? (expf(z[c] - mx) * inv - (c == lab ? 1.0f : 0.0f)) * grad_scale : NAN;
                 d[c] = f32_to_bf16(g);
             }
         }
@@ -187,12 +200,14 @@ __global__ void __launch_bounds__(256) cast_transpose_kernel(const float* __rest
     }
 }
 
-__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+template <bool ZERO_G>
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     const uint8_t* __restrict__ flags, int64_t n4, float lr_t, float b1c, float b2c, float eps,
                                                     float wd, float gscale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        if (ZERO_G) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the next backward accumulates into zeros
         float4 mv = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         const bool decay = flags ? (flags[i >> 8] != 0) : true;  // 1024-element chunks = 256 float4
@@ -210,6 +225,11 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
         reinterpret_cast<float4*>(m)[i] = mv;
         reinterpret_cast<float4*>(v)[i] = vv;
     }
+}
+
+__global__ void __launch_bounds__(256) zero_f32_kernel(float* __restrict__ x, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(x)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---- token pooling over the patch tokens 1..N-1 (pooling="avg" | "max" | "sum"); one thread = one (image, column pair)
@@ -289,9 +309,32 @@ __global__ void __launch_bounds__(256) tanh_bwd_kernel(const float* __restrict__
 
 }  // namespace
 
+int chb_option(int id) {
+    if (id < 0 || id >= CHB_OPT_COUNT) return 0;
+    if (!g_option_read[id].load(std::memory_order_acquire)) {
+        char env[64] = "CHB_";
+        strncat(env, kOptions[id].name, sizeof(env) - 5);
+        const char* e = getenv(env);
+        g_option[id].store(e ? atoi(e) : kOptions[id].dflt, std::memory_order_relaxed);
+        g_option_read[id].store(true, std::memory_order_release);
+    }
+    return g_option[id].load(std::memory_order_relaxed);
+}
+
 extern "C" {
 
-int chb_version(void) { return 1; }
+int chb_set_option(const char* name, int value) {
+    if (!name) return CHB_EINVAL;
+    for (int id = 0; id < CHB_OPT_COUNT; ++id)
+        if (!strcmp(name, kOptions[id].name)) {
+            g_option[id].store(value, std::memory_order_relaxed);
+            g_option_read[id].store(true, std::memory_order_release);
+            return CHB_OK;
+        }
+    return CHB_EINVAL;
+}
+
+int chb_version(void) { return 2; }
 const char* chb_build_arch(void) { return "gfx950"; }
 
 int chb_dropout_mask(uint8_t* out, int64_t n, float rate, uint32_t key, void* stream) {
@@ -416,12 +459,25 @@ int chb_cast_transpose(const float* src, void* dst, void* dst_t, const int64_t* 
     return CHB_OK;
 }
 
-int chb_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay_flags, int64_t n, float lr_t, float beta1, float beta2,
-              float eps, float weight_decay, float grad_scale, void* stream) {
+int chb_adamw(float* p, float* g, float* m, float* v, const uint8_t* decay_flags, int64_t n, float lr_t, float beta1, float beta2,
+              float eps, float weight_decay, float grad_scale, int zero_grad, void* stream) {
     if (!p || !g || !m || !v || n < 0 || (n & 3)) return CHB_EINVAL;
     if (n == 0) return CHB_OK;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, decay_flags, n / 4, lr_t,
-                       1.0f - beta1, 1.0f - beta2, eps, weight_decay, grad_scale);
+    if (zero_grad)
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, decay_flags, n / 4, lr_t,
+                           1.0f - beta1, 1.0f - beta2, eps, weight_decay, grad_scale);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, decay_flags, n / 4, lr_t,
+                           1.0f - beta1, 1.0f - beta2, eps, weight_decay, grad_scale);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_zero_f32(float* x, int64_t n, void* stream) {
+    if (n < 0 || (n && !x)) return CHB_EINVAL;
+    if (n == 0) return CHB_OK;
+    if (((uintptr_t)x & 15) || (n & 3)) return CHB_EINVAL;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(grid_for(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, x, n / 4);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

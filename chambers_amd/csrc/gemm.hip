@@ -1245,14 +1245,7 @@ int num_cus() {
 }
 
 // 0 = automatic, 1 = 128x128 tiles (one workgroup per tile), 2 = persistent 256x256 tiles, 3 = persistent 128x256 x 2 WG/CU
-int gemm_algo_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("CHB_GEMM_ALGO");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+int gemm_algo_override() { return chb_option(CHB_OPT_GEMM_ALGO); }
 
 template <int EPI>
 int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
@@ -1327,10 +1320,7 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
     p.drop_key = drop_key;
     p.tiles_m = chb_div_up(M, BM); p.tiles_n = chb_div_up(N, BN);
     p.colsum = out_colsum;
-    {
-        const char* e = getenv("CHB_GEMM_WALK");   // 0 = linear tile ids per XCD, 1 (default) = panel walk where it pays, 2 = always panel
-        p.walk_panel = e ? atoi(e) : 1;
-    }
+    p.walk_panel = chb_option(CHB_OPT_GEMM_WALK);   // 0 = linear tile ids per XCD, 1 (default) = panel walk where it pays, 2 = always panel
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         int rc;
@@ -1368,9 +1358,9 @@ static Tn256Plan tn256_plan(int M, int Kd, int Nd, const float* workspace, int64
     pl.splits = chb_div_up(steps, pl.steps_per_split);
     // partial planes + one fold launch when the caller lends enough scratch (and the fold's float4 accesses are aligned)
     const int64_t need = (int64_t)pl.splits * Kd * Nd * 4;
-    const char* e = getenv("CHB_TN_ATOMICS");     // 1 = always the atomic epilogue (A/B timing)
+    const bool force_atomics = chb_option(CHB_OPT_TN_ATOMICS) == 1;     // A/B timing
     pl.planes = pl.use256 && workspace && workspace_bytes >= need && pl.splits > 1 && !(Nd & 3) && !(ldw & 3) &&
-                !((uintptr_t)workspace & 15) && !((uintptr_t)dW & 15) && !(e && atoi(e) == 1);
+                !((uintptr_t)workspace & 15) && !((uintptr_t)dW & 15) && !force_atomics;
     return pl;
 }
 
@@ -1405,8 +1395,7 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
             q.ws = pl.planes ? workspace : nullptr;
             q.colsum = dy_colsum;
             const dim3 grid(pl.tiles_k * pl.tiles_n * q.splits);
-            const char* fe = getenv("CHB_TN_FAST");        // 0 = generic staging addresses everywhere (A/B timing)
-            const bool fast = !(Kd & 255) && !(Nd & 255) && !(fe && atoi(fe) == 0);
+            const bool fast = !(Kd & 255) && !(Nd & 255) && chb_option(CHB_OPT_TN_FAST) != 0;   // 0 = generic staging addresses (A/B timing)
             hipStream_t st = (hipStream_t)stream;
             if (dy_colsum) {
                 if (fast) hipLaunchKernelGGL((gemm_tn256_kernel<true, true>), grid, dim3(512), 0, st, q);

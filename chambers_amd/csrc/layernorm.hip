@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, float* __restrict__ dx, int64_t dx_stride,
                                                      int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
                                                      int D, bf16_t* __restrict__ dz, float* __restrict__ dzsum, float drop_scale,
-                                                     uint32_t drop_thr, uint32_t drop_key) {
+                                                     uint32_t drop_thr, uint32_t drop_key, int zero_gaps) {
     __shared__ float red[3][4][NCH * 256];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nchunk = D >> 2;
@@ -144,6 +144,19 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
             }
         }
     }
+    if (zero_gaps) {
+        // strided rows (the class rows of the token matrix: dx_stride = N * D): this launch also owns the floats between them.
+        // Row r's gap is dx[r * dx_stride + D .. (r + 1) * dx_stride); it is cut into 64 KiB pieces dealt over the whole grid.
+        const int64_t gap4 = (dx_stride - D) >> 2;
+        const int64_t parts = (gap4 + 4095) >> 12;
+        const int64_t items = (int64_t)M * parts;
+        for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+            const int64_t row = it / parts, part = it - row * parts;
+            float4* base = reinterpret_cast<float4*>(dx + row * dx_stride + D) + (part << 12);
+            const int64_t cnt = min((int64_t)4096, gap4 - (part << 12));
+            for (int64_t k = threadIdx.x; k < cnt; k += 256) base[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     // block-level reduce of dgamma/dbeta partials over the 4 waves, then one atomic per column
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -196,9 +209,10 @@ int chb_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, cons
 
 int chb_layernorm_bwd(const void* dy, const float* x, int64_t x_stride, const float* mean, const float* rstd, const float* gamma,
                       float* dx, int64_t dx_stride, int accumulate, float* dgamma, float* dbeta, int M, int D, void* dz_bf16,
-                      float* dz_colsum, float drop_rate, uint32_t drop_key, void* stream) {
+                      float* dz_colsum, float drop_rate, uint32_t drop_key, int zero_gaps, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || M < 0 || D <= 0) return CHB_EINVAL;
     if (drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
+    if (zero_gaps && (accumulate || dx_stride < D)) return CHB_EINVAL;
     bf16_t* dz = (bf16_t*)dz_bf16;
     const float dscale = 1.0f / (1.0f - drop_rate);
     const uint32_t dthr = drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u;
@@ -206,15 +220,15 @@ int chb_layernorm_bwd(const void* dy, const float* x, int64_t x_stride, const fl
     if (M == 0) return CHB_OK;
     const int nch = (D / 4 + 63) / 64;
     int blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 1024 || (zero_gaps && dx_stride > D)) blocks = 1024;    // the gap fill wants the whole chip
     const dim3 grid(blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* d = (const bf16_t*)dy;
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key); break;
-        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key); break;
-        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key); break;
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); break;
+        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); break;
     }
     CHB_LAUNCH_CHECK();
     return CHB_OK;

@@ -379,11 +379,9 @@ class ViTEngine:
             self.G = torch.zeros(nflat, dtype=f32, device=dev)
             self.Mo = torch.zeros(nflat, dtype=f32, device=dev)
             self.Vo = torch.zeros(nflat, dtype=f32, device=dev)
-            flags = np.zeros(nflat // ALIGN, dtype=np.uint8)
-            for s in self.specs:
-                flags[s.offset // ALIGN:_round_up(s.offset + s.size, ALIGN) // ALIGN] = 1 if s.decay else 0
-            self.decay_flags = torch.as_tensor(flags, device=dev)
+            self._upload_decay_flags()
             self.reducer = GradBucketReducer(self.G, self.buckets, process_group)
+            self._g_clean = True        # G holds zeros (allocation, or the last AdamW launch cleared it behind its read)
         mats = [s for s in self.specs if s.matrix]
         desc = np.array([[s.offset, s.offset, s.shape[0], s.shape[1]] for s in mats], dtype=np.int64)
         self.ct_desc = torch.as_tensor(desc, device=dev)
@@ -391,6 +389,20 @@ class ViTEngine:
         self.ct_tiles = max(((s.shape[0] + 63) // 64) * ((s.shape[1] + 63) // 64) for s in mats)
         self.opt_step = 0
         self._alloc_activations()
+
+    def _upload_decay_flags(self):
+        flags = np.zeros(self.n_params_padded // ALIGN, dtype=np.uint8)
+        for s in self.specs:
+            flags[s.offset // ALIGN:_round_up(s.offset + s.size, ALIGN) // ALIGN] = 1 if s.decay else 0
+        self.decay_flags = torch.as_tensor(flags, device=self.dev)
+
+    def set_decay_fn(self, decay_fn):
+        """Re-derive which tensors AdamW decays (optimizers.py:169-181) without touching weights, Adam moments or the step
+        count: `Model.compile` with another optimizer keeps the training state, as Keras does."""
+        for s in self.specs:
+            s.decay = True if decay_fn is None else bool(decay_fn(s.name))
+        if self.training:
+            self._upload_decay_flags()
 
     # ---- views --------------------------------------------------------------------------
     def _v(self, buf, name):
@@ -641,8 +653,12 @@ class ViTEngine:
         d, ff, n, M, Mp = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens, self.M, self.Mp
         L = cfg.n_encoder_layers
         F = cfg.feature_dim
-        self.G.zero_()
-        self.dx.zero_()
+        # a collective of the previous backward may still be reading / writing slices of G (backward called twice without an
+        # optimizer step): drain it before G is touched
+        self.reducer.finish()
+        if not self._g_clean:
+            K.zero_f32(self.G)          # only when backward runs twice without adamw_step; AdamW clears G behind its read
+        self._g_clean = False
         # heads
         if cfg.distilled:
             self._distilled_heads_backward(doutput)
@@ -667,8 +683,9 @@ class ViTEngine:
             K.gemm_nt(self.dfz, self.wb("feature/kernel"), self.dhf, m=self.B)
         # pooling + final norm
         if cfg.pooling == "cls":
+            # the class rows get their gradient, every other row of dx its zero, in one launch (zero_gaps)
             K.layernorm_bwd(self.dhf, self.x_final, n * d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, n * d, False,
-                            self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
+                            self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d, zero_gaps=True)
             if cfg.distilled:   # the distillation token's rows (sequence row 1) of the same LayerNorm
                 K.layernorm_bwd(self.dhfd, self.x_final.view(-1)[d:], n * d, self.meand, self.rstdd, self.p("encoder/norm/gamma"),
                                 self.dx.view(-1)[d:], n * d, False, self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
@@ -755,15 +772,18 @@ class ViTEngine:
             self.dhfd[:self.B].copy_(db)
 
     # ---- optimizer ------------------------------------------------------------------------
-    def adamw_step(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, weight_decay=0.0):
-        """chambers.optimizers.AdamW semantics (decay first, wd not scaled by lr, keras Adam epsilon-hat form)."""
+    def adamw_step(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, weight_decay=0.0, zero_grad=True):
+        """chambers.optimizers.AdamW semantics (decay first, wd not scaled by lr, keras Adam epsilon-hat form).  zero_grad: the
+        update clears each gradient element right after reading it, so the next backward starts from zeros without a fill pass
+        (export_keras_grads() must be called before this, or pass zero_grad=False)."""
         self.reducer.finish()
         self.opt_step += 1
         t = self.opt_step
         b1, b2 = np.float32(beta_1), np.float32(beta_2)
         lr_t = np.float32(learning_rate) * np.sqrt(np.float32(1.0) - np.power(b2, np.float32(t))) / (np.float32(1.0) - np.power(b1, np.float32(t)))
         K.adamw(self.P, self.G, self.Mo, self.Vo, self.decay_flags, float(lr_t), beta_1, beta_2, epsilon, weight_decay,
-                self.reducer.grad_scale)
+                self.reducer.grad_scale, zero_grad=zero_grad)
+        self._g_clean = bool(zero_grad)
         self.refresh_operands()
 
     def train_step(self, images_u8, labels, **opt):

@@ -92,6 +92,51 @@ def aug_sharpness(x, factor):
     return out
 
 
+AUG_ITEM_DTYPE = np.dtype([("op", np.int32), ("i", np.int32, (4,)), ("pad", np.int32, (3,)), ("f", np.float32, (8,))])   # 64 bytes
+
+
+def aug_item(op, i=(), f=()):
+    """One record of chb_aug_dispatch: op id (_lib.AUG_*), up to 4 integer and 8 float parameters."""
+    rec = np.zeros((), dtype=AUG_ITEM_DTYPE)
+    rec["op"] = int(op)
+    for k, v in enumerate(i):
+        rec["i"][k] = int(v)
+    for k, v in enumerate(f):
+        rec["f"][k] = np.float32(v)
+    return rec
+
+
+def aug_dispatch(x, items, out=None):
+    """One slot of an elementwise scheme: items = numpy array [B] of AUG_ITEM_DTYPE (per-image op + parameters)."""
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    if c != 3:
+        raise ValueError("per-image dispatch handles RGB batches (the schemes' InputSpec), got %d channels" % c)
+    items = np.ascontiguousarray(items, dtype=AUG_ITEM_DTYPE)
+    if items.shape != (b,):
+        raise ValueError("expected %d op records, got %s" % (b, items.shape))
+    n_stats = int(np.isin(items["op"], (_lib.AUG_AUTOCONTRAST, _lib.AUG_EQUALIZE)).sum())
+    dev = torch.as_tensor(items.view(np.uint8).reshape(b, 64), device=x.device)
+    ws = torch.empty(max(b * 768, 1), dtype=torch.int32, device=x.device) if n_stats else None
+    out = torch.empty_like(x) if out is None else out
+    _lib.call("chb_aug_dispatch", _lib.ptr(x), _lib.ptr(out), b, h, w, _lib.ptr(dev), n_stats, _lib.ptr(ws), _s())
+    return out
+
+
+def concat_batch(parts):
+    """Batch-axis concatenation of same-shaped image tensors by device-to-device copies into one allocation (the
+    image-by-image route of elementwise schemes with user-supplied transforms)."""
+    if not parts:
+        raise ValueError("nothing to concatenate")
+    total = sum(int(p.shape[0]) for p in parts)
+    out = torch.empty((total,) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, device=parts[0].device)
+    at = 0
+    for p in parts:
+        out[at:at + p.shape[0]].copy_(p)
+        at += p.shape[0]
+    return out
+
+
 def normalize(x, mode):
     _lib.require_gpu(x)
     if mode not in NORM_MODES:
@@ -280,13 +325,13 @@ def layernorm_fwd(x, x_stride, gamma, beta, y, mean, rstd, m, d, eps):
 
 
 def layernorm_bwd(dy, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, m, d, dz=None, dz_colsum=None,
-                  drop_rate=0.0, drop_key=0):
+                  drop_rate=0.0, drop_key=0, zero_gaps=False):
     _lib.require_gpu(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dz, dz_colsum)
     if dz is not None and int(dx_stride) != int(d):
         raise ValueError("the fused dropout-backward tail needs compact rows")
     _lib.call("chb_layernorm_bwd", _lib.ptr(dy), _lib.ptr(x), int(x_stride), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dx),
               int(dx_stride), int(bool(accumulate)), _lib.ptr(dgamma), _lib.ptr(dbeta), int(m), int(d), _lib.ptr(dz), _lib.ptr(dz_colsum),
-              float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+              float(drop_rate), ctypes.c_uint32(int(drop_key)), int(bool(zero_gaps)), _s())
     return dx
 
 
@@ -385,7 +430,15 @@ def cast_transpose(src, dst, dst_t, desc, n_desc, max_tiles):
     _lib.call("chb_cast_transpose", _lib.ptr(src), _lib.ptr(dst), _lib.ptr(dst_t), _lib.ptr(desc), int(n_desc), int(max_tiles), _s())
 
 
-def adamw(p, g, m, v, flags, lr_t, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+def adamw(p, g, m, v, flags, lr_t, beta1, beta2, eps, weight_decay, grad_scale=1.0, zero_grad=False):
     _lib.require_gpu(p, g, m, v, flags)
     _lib.call("chb_adamw", _lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(flags), p.numel(), float(lr_t), float(beta1), float(beta2),
-              float(eps), float(weight_decay), float(grad_scale), _s())
+              float(eps), float(weight_decay), float(grad_scale), int(bool(zero_grad)), _s())
+
+
+def zero_f32(x):
+    _lib.require_gpu(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("zero_f32 expects a contiguous float32 tensor")
+    _lib.call("chb_zero_f32", _lib.ptr(x), x.numel(), _s())
+    return x

@@ -57,6 +57,8 @@ class Model(Layer):
         self.built = True
         self._engines = {}
         self._loaded_version = {}
+        self._dirty = None          # key of the training engine whose weights are newer than the layer variables
+        self._decay_key = {}        # engine key -> id of the optimizer whose decay flags it carries
 
     def _sublayers(self):
         return list(self.layers)
@@ -71,8 +73,33 @@ class Model(Layer):
     def input_shape(self):
         return (None,) + self.cfg.image_size + (3,)
 
+    # ---- trained weights live in the training engine's flat buffer until somebody looks at the layer variables
+    def _sync(self):
+        """After train_step the newest weights are in the training engine (fp32 master buffer in HBM).  Every reader of the
+        layer variables (call / predict, keras_weights, get_weights, save_weights, compile, the engines of other batch sizes)
+        goes through here first, so `train_step` followed by `model(x)` behaves like Keras fit followed by predict.  The
+        training engine itself is marked current afterwards: it keeps its Adam moments and step count."""
+        key = self._dirty
+        if key is None:
+            return
+        self._dirty = None
+        self._assign(self._engines[key].export_keras_weights())
+        self._loaded_version[key] = self._version
+
+    @property
+    def weights(self):
+        self._sync()
+        return Layer.weights.fget(self)
+
+    trainable_weights = weights
+
+    def set_weights(self, weights):
+        self._sync()
+        super().set_weights(weights)
+
     # ---- Keras-named weight dictionary <-> layer variables
     def keras_weights(self):
+        self._sync()
         kw = {}
         emb = self.get_layer("patch_embeddings").get_layer("embedding")
         kw["patch_embeddings/embedding/kernel"], kw["patch_embeddings/embedding/bias"] = emb.kernel.numpy(), emb.bias.numpy()
@@ -100,6 +127,10 @@ class Model(Layer):
         return kw
 
     def assign_keras_weights(self, kw):
+        self._dirty = None          # an explicit assignment supersedes whatever a training engine holds
+        self._assign(kw)
+
+    def _assign(self, kw):
         emb = self.get_layer("patch_embeddings").get_layer("embedding")
         emb.kernel.assign(kw["patch_embeddings/embedding/kernel"]); emb.bias.assign(kw["patch_embeddings/embedding/bias"])
         self.get_layer("add_cls_token").embedding.assign(kw["add_cls_token/embeddings"])
@@ -139,6 +170,8 @@ class Model(Layer):
     # ---- execution
     def engine(self, batch_size, training=False, **kw):
         key = (int(batch_size), bool(training))
+        if self._dirty is not None and self._dirty != key:
+            self._sync()
         if key not in self._engines:
             self._engines[key] = E.ViTEngine(self.cfg, batch_size, training=training, **kw)
             self._loaded_version[key] = -1
@@ -171,31 +204,42 @@ class Model(Layer):
         """keras Model.compile for the part the hot path uses: a chambers_amd.optimizers.AdamW (hyper-parameters may be
         schedules, e.g. chambers_amd.schedules.LinearWarmup; decay_include / decay_exclude select the decayed variables).
         The loss is the fused sparse softmax cross-entropy from logits."""
+        self._sync()
         self.optimizer = optimizer
-        self._engines = {k: v for k, v in self._engines.items() if not k[1]}   # training engines bake the decay flags in
+        self._decay_key = {}        # training engines keep weights, Adam moments and step count; their decay flags are re-derived
 
     def train_step(self, images_u8, labels, **opt):
         """One optimisation step on an (augmented) uint8 NHWC batch; returns the per-sample loss.  Uses the compiled
         optimizer if there is one, else AdamW with the keyword hyper-parameters given here."""
         optimizer = getattr(self, "optimizer", None)
+        key = (int(images_u8.shape[0]), True)
         if optimizer is None:
-            return self.engine(images_u8.shape[0], training=True).train_step(images_u8, labels, **opt)
+            eng = self.engine(key[0], training=True)
+            if self._decay_key.get(key) is not None:
+                eng.set_decay_fn(None)
+                self._decay_key[key] = None
+            loss = eng.train_step(images_u8, labels, **opt)
+            self._dirty = key
+            return loss
         if opt:
             raise ValueError("hyper-parameters come from the compiled optimizer; got %s" % sorted(opt))
-        eng = self.engine(images_u8.shape[0], training=True, decay_fn=optimizer.decay_fn(self.cfg))
         if not self.cfg.include_top:
             raise ValueError("train_step needs the classification top (include_top=True)")
+        eng = self.engine(key[0], training=True)
+        if self._decay_key.get(key) != id(optimizer):
+            eng.set_decay_fn(optimizer.decay_fn(self.cfg))
+            self._decay_key[key] = id(optimizer)
         eng.forward(images_u8, training=True)
         loss = eng.loss(labels)
         eng.backward()
         optimizer.apply(eng)
+        self._dirty = key
         return loss
 
-    def sync_from_engine(self, batch_size):
-        """Copy trained weights back into the layer variables (Keras layout)."""
-        eng = self._engines[(int(batch_size), True)]
-        self.assign_keras_weights(eng.export_keras_weights())
-        self._loaded_version[(int(batch_size), True)] = self._version
+    def sync_from_engine(self, batch_size=None):
+        """Copy trained weights back into the layer variables (Keras layout).  Kept for callers of the round-1 API: every
+        reader of the variables now does this lazily (`_sync`)."""
+        self._sync()
 
 
 def VisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate=0.1, input_tensor=None, input_shape=None,

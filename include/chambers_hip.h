@@ -37,6 +37,21 @@ extern "C" {
 #define CHB_PW_CONTRAST 5     /* :253-265   factor, i0 = degenerate constant (host: pixels/256 clipped) */
 #define CHB_PW_COLOR 6        /* :233-235   factor; 3 channels */
 
+/* per-image op ids for chb_aug_dispatch (one 64-byte record per image, see chb_aug_dispatch) */
+#define CHB_AUG_IDENTITY 0      /* RandomChance not taken (:522-529) */
+#define CHB_AUG_AUTOCONTRAST 1  /* :63-90 */
+#define CHB_AUG_EQUALIZE 2      /* :94-103 */
+#define CHB_AUG_INVERT 3        /* :107-116 */
+#define CHB_AUG_POSTERIZE 4     /* i0 = shift */
+#define CHB_AUG_SOLARIZE 5      /* i0 = threshold */
+#define CHB_AUG_SOLARIZE_ADD 6  /* i0 = threshold, i1 = addition */
+#define CHB_AUG_BRIGHTNESS 7    /* f[0] = factor */
+#define CHB_AUG_CONTRAST 8      /* f[0] = factor, i0 = degenerate constant of a batch-1 tensor (H*W/256 clipped, :260-262) */
+#define CHB_AUG_COLOR 9         /* f[0] = factor */
+#define CHB_AUG_SHARPNESS 10    /* f[0] = factor */
+#define CHB_AUG_AFFINE 11       /* f[0..5] = a0 a1 a2 b0 b1 b2 (output -> input, tfa.image.transform), i0 = fill value */
+#define CHB_AUG_CUTOUT 12       /* i0 = cy, i1 = cx, i2 = mask_size / 2, i3 = constant value */
+
 #define CHB_NORM_CAFFE 0 /* :647-650 */
 #define CHB_NORM_TF 1    /* :659-665 */
 #define CHB_NORM_TORCH 2 /* :652-657 */
@@ -140,10 +155,14 @@ int chb_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, cons
 /* dx[row] (+)= LN'(dy); dgamma/dbeta fp32 [D] accumulated with atomics (caller zeroes).
  * Optional fused tail (dz_bf16 != NULL): the backward of the keras Dropout that precedes this residual sum in
  * forward order (layers/transformer.py:69,76) — dz[M,D] = bf16(dx * keep / (1-rate)) (dx_stride must be D), the
- * operand of the next dgrad/wgrad GEMMs, and dz_colsum[D] += its column sums (that layer's bias gradient). */
+ * operand of the next dgrad/wgrad GEMMs, and dz_colsum[D] += its column sums (that layer's bias gradient).
+ * zero_gaps != 0 (needs accumulate == 0): the launch also zero-fills the floats between consecutive rows,
+ * dx[r*dx_stride + D .. (r+1)*dx_stride) — with pooling="cls" (vision_transformer.py:182-189) only the class rows of the
+ * final LayerNorm carry a gradient and every other row of the residual gradient starts at zero. */
 int chb_layernorm_bwd(const void* dy_bf16, const float* x, int64_t x_stride, const float* mean, const float* rstd,
                       const float* gamma, float* dx, int64_t dx_stride, int accumulate, float* dgamma, float* dbeta,
-                      int M, int D, void* dz_bf16, float* dz_colsum, float drop_rate, uint32_t drop_key, void* stream);
+                      int M, int D, void* dz_bf16, float* dz_colsum, float drop_rate, uint32_t drop_key, int zero_gaps,
+                      void* stream);
 
 /* MultiHeadAttention core (layers/attention.py:7-23,113-125): softmax(QK^T/sqrt(hd)) with
  * dropout on the probabilities, times V.  qkv bf16 [B*N, 3*H*hd] = [Q heads | K heads | V heads];
@@ -205,7 +224,9 @@ int chb_dropout_bwd_bf16(const float* dy, int64_t ld, void* dz_bf16, int M, int 
 /* out[N] += column sums of bf16 x[M,ld] (bias gradients). */
 int chb_colsum_bf16(const void* x, int64_t ld, float* out, int M, int N, void* stream);
 /* sparse softmax cross-entropy from logits (mean over batch) + gradient:
- * loss_per_sample fp32 [B]; dlogits bf16 [B,ld_d] = (softmax - onehot) * grad_scale, pad cols 0. */
+ * loss_per_sample fp32 [B]; dlogits bf16 [B,ld_d] = (softmax - onehot) * grad_scale, pad cols 0.
+ * Labels are range-checked on the device: a label outside [0, classes) gives loss = NaN and a NaN gradient row
+ * (never an out-of-bounds read of the logits). */
 int chb_softmax_ce(const float* logits, int64_t ld, const int32_t* labels, float* loss_per_sample, void* dlogits_bf16,
                    int64_t ld_d, int B, int classes, float grad_scale, void* stream);
 /* pooling="cls" needs no kernel: chb_layernorm_* take the row stride N*D and touch the cls rows only.
@@ -247,9 +268,29 @@ int chb_cast_transpose(const float* src, void* dst_bf16, void* dst_t_bf16, const
 
 /* AdamW (optimizers.py:147-155,372-464 + keras Adam): per element, if decay flag of its
  * 1024-element chunk is set: p -= wd*p; then m += (g-m)(1-b1); v += (g*g-v)(1-b2);
- * p -= lr_t*m/(sqrt(v)+eps).  grad_scale multiplies g first (1/world for data parallel). */
-int chb_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay_flags, int64_t n, float lr_t,
-              float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+ * p -= lr_t*m/(sqrt(v)+eps).  grad_scale multiplies g first (1/world for data parallel).
+ * zero_grad != 0: g[i] = 0 right behind its read, so the next backward accumulates into zeros without a fill pass
+ * (what keras' apply_gradients + a fresh GradientTape amount to). */
+int chb_adamw(float* p, float* g, float* m, float* v, const uint8_t* decay_flags, int64_t n, float lr_t,
+              float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, void* stream);
+/* RandomChoice(elementwise=True) (image_augmentations.py:563-570: tf.map_fn of `_random_transforms` over batch-1 tensors,
+ * :606-617) and the elementwise modes of RandAugment / AutoAugment (augmentation_schemes.py:138-149,193): ONE slot of the
+ * scheme for the whole batch, every image with its own op and parameters.  items_dev: B records of 64 bytes on the device,
+ *   struct { int32 op; int32 i0, i1, i2, i3; int32 pad[3]; float f[8]; }   (op = CHB_AUG_*, fields as listed there),
+ * written by the host from the per-image decisions (op index, sign draw, cutout centre; Contrast's constant is that of a
+ * batch-1 tensor).  n_stats = number of images whose op is AutoContrast / Equalize (0 skips the histogram and table
+ * launches); workspace int32 [B*3*256] is needed when n_stats > 0.  uint8 NHWC RGB, in != out.  Results equal the
+ * batch ops above applied image by image, bit for bit. */
+int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const void* items_dev, int n_stats,
+                     int32_t* workspace, void* stream);
+
+/* Tuning / A-B switch `name` (ATTN_FWD_ALGO, ATTN_BWD_ALGO, AFFINE_ALGO, GEMM_ALGO, GEMM_WALK, TN_ATOMICS, TN_FAST,
+ * GEMM_EPI_OVERLAP; csrc/common.hpp) := value.  Defaults come from the environment variables CHB_<name>, read once per
+ * process; nothing on the launch path calls getenv.  Results are identical under every setting (the parity tests
+ * cross-check them); only speed changes. */
+int chb_set_option(const char* name, int value);
+/* x[0..n) = 0 (n % 4 == 0, 16-byte aligned): gradient buffer reset when backward runs twice without an optimizer step. */
+int chb_zero_f32(float* x, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -447,6 +447,25 @@ def auto_augment(x, decision):
     return x
 
 
+def rand_augment_elementwise(x, n_transforms, magnitude, decisions):
+    """RandAugment(elementwise=True): RandomChoice.call maps `_random_transforms` over the batch with tf.map_fn, each image
+    expanded to a batch-1 tensor (image_augmentations.py:563-570).  So every image has its own op indices, its own sign
+    draws and cutout centre, and Contrast's degenerate constant is that of ONE image (H*W/256 clipped, :260-262).
+    ``decisions[n]`` = the list of n_transforms dicts for image n ("centers": [1,2] or [2])."""
+    outs = []
+    for n in range(x.shape[0]):
+        ds = [dict(d, centers=np.asarray(d["centers"]).reshape(1, 2)) if d.get("centers") is not None else d for d in decisions[n]]
+        outs.append(rand_augment(x[n:n + 1], n_transforms, magnitude, ds))
+    return np.concatenate(outs, axis=0) if outs else np.array(x, copy=True)
+
+
+def auto_augment_elementwise(x, decisions):
+    """AutoAugment(elementwise=True) (augmentation_schemes.py:135,147-149): one decision (sub-policy, two chance draws, two
+    sign draws) per image, each image a batch-1 tensor."""
+    outs = [auto_augment(x[n:n + 1], decisions[n]) for n in range(x.shape[0])]
+    return np.concatenate(outs, axis=0) if outs else np.array(x, copy=True)
+
+
 # --------------------------------------------------------------------------- #
 # input side: keras preprocessing layers re-exported by chambers.augmentations
 # (augmentations/__init__.py:1-13) and chambers' ResizingMinMax (:686-748).

@@ -48,6 +48,22 @@ VIT_CFG = {"patch_size": 16, "patch_dim": 64, "n_encoder_layers": 2, "n_heads": 
 VIT_SEED, VIT_STEP = 7, 0
 
 
+def elementwise_randaugment_decisions(shape):
+    """Fixed per-image decisions that walk all 16 ops over the images of the two fixture batches (image n: ops
+    (5n + 4) % 16 then (5n + 9) % 16 ... so Contrast, both statistics ops, every warp and CutOut occur)."""
+    b, h, w, _ = shape
+    table = [(4, 1), (0, 7), (14, 6), (15, 10), (12, 2)]       # Contrast+Equalize, AutoContrast+ShearX, CutOut+Sharpness, Rotate+TranslateY, Solarize+Invert
+    return [[{"op": table[(n + k) % 5][j] if k == 0 else (3 * n + 5 * j + 9) % 16, "negate": bool((n + j) & 1),
+              "centers": np.array([[(7 * n + 3 * j + 2) % h, (5 * n + j + 1) % w]], dtype=np.int32)} for j in range(2)]
+            for n in range(b) for k in (0,)]
+
+
+def elementwise_autoaugment_decisions(shape):
+    b = shape[0]
+    pols = [0, 12, 22, 15, 7]
+    return [{"policy": pols[n % 5], "apply": (bool((n + 1) & 1), True), "negate": (bool(n & 1), bool((n >> 1) & 1))} for n in range(b)]
+
+
 def augment_fixture():
     g = np.random.Generator(np.random.PCG64(0))
     out = {}
@@ -62,6 +78,9 @@ def augment_fixture():
         out["randaugment_%s" % tag] = A.rand_augment(x, 2, 9, dec)
         out["autoaugment_p3_%s" % tag] = A.auto_augment(x, {"policy": 3, "apply": (True, True), "negate": (False, True)})
         out["autoaugment_p22_%s" % tag] = A.auto_augment(x, {"policy": 22, "apply": (True, True), "negate": (False, False)})
+        # elementwise=True (tf.map_fn over batch-1 tensors): per-image op / sign / centre; Contrast's constant is H*W/256 of ONE image
+        out["randaugment_elementwise_%s" % tag] = A.rand_augment_elementwise(x, 2, 9, elementwise_randaugment_decisions(shape))
+        out["autoaugment_elementwise_%s" % tag] = A.auto_augment_elementwise(x, elementwise_autoaugment_decisions(shape))
         for mode in ("tf", "torch", "caffe"):
             out["normalize_%s_%s" % (mode, tag)] = A.imagenet_normalize(x, mode)
         # input side (Resizing / CenterCrop / RandomCrop / RandomFlip / Rescaling)

@@ -207,3 +207,42 @@ def test_deit_builder_outputs_and_timm_import():
     ref2 = vit_ref.vit_forward({k: torch.tensor(v) for k, v in kw2.items()}, torch.from_numpy(A.imagenet_normalize(images, "tf")),
                                m.cfg.as_oracle_cfg(), bf16=True)
     assert rel_l2(out2[1], ref2[1]) < 4e-3
+
+
+def test_train_step_then_predict_uses_trained_weights_without_manual_sync():
+    """Keras fit followed by predict / get_weights / save_weights: the trained weights are what every reader sees, the training
+    engine keeps its Adam state across compile(), and an explicit set_weights supersedes the engine."""
+    from chambers_amd.models.backbones.vision_transformer import VisionTransformer
+    from chambers_amd.optimizers import AdamW
+    m = VisionTransformer(patch_size=16, patch_dim=64, n_encoder_layers=2, n_heads=1, ff_dim=128, dropout_rate=0.0, input_shape=(32, 32, 3),
+                          weights=None, classes=5)
+    g = np.random.Generator(np.random.PCG64(3))
+    x = torch.as_tensor(g.integers(0, 256, size=(4, 32, 32, 3), dtype=np.uint8), device="cuda")
+    y = torch.as_tensor(g.integers(0, 5, size=(4,)), device="cuda")
+    before = m(x).clone()
+    w_before = [w.copy() for w in m.get_weights()]
+    for _ in range(5):
+        m.train_step(x, y, learning_rate=1e-2)
+    after = m(x).clone()                                       # no sync_from_engine
+    assert float((after - before).abs().max()) > 1e-3
+    w_after = m.get_weights()
+    assert any(float(np.abs(a - b).max()) > 1e-4 for a, b in zip(w_after, w_before))
+    eng = m.engine(4, training=True)
+    assert eng.opt_step == 5
+    # the inference engine and the training engine agree on the weights
+    exported = eng.export_keras_weights()
+    kw = m.keras_weights()
+    for k in kw:
+        np.testing.assert_array_equal(kw[k], exported[k])
+    # compile keeps weights, Adam moments and the step count
+    mo = eng.Mo.clone()
+    m.compile(optimizer=AdamW(weight_decay=0.01, learning_rate=1e-3, decay_exclude=["bias", "gamma", "beta", "embeddings"]))
+    assert m.engine(4, training=True) is eng and torch.equal(eng.Mo, mo)
+    np.testing.assert_array_equal(m.keras_weights()["predictions/kernel"], exported["predictions/kernel"])
+    m.train_step(x, y)
+    assert eng.opt_step == 6
+    spec = eng.by_name["encoder/layer_0/dense1/bias"]
+    assert not spec.decay and eng.by_name["encoder/layer_0/dense1/kernel"].decay
+    # set_weights after training replaces what the engine holds
+    m.set_weights(w_before)
+    np.testing.assert_allclose(m(x).cpu().numpy(), before.cpu().numpy(), rtol=0, atol=0)

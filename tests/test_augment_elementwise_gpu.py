@@ -1,0 +1,161 @@
+"""GPU parity of the per-image (elementwise=True) augmentation path: RandomChoice / RandAugment / AutoAugment with
+`elementwise=True` run ONE dispatch launch per slot (chb_aug_dispatch) and must equal the oracle applied image by image
+to batch-1 tensors — the semantics of the reference's tf.map_fn (image_augmentations.py:563-570, 606-617;
+augmentation_schemes.py:138-149,193): per-image op index, per-image sign draw, per-image cutout centre, and Contrast's
+constant computed from ONE image (196 for 224x224).  Bit-exact, uint8."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_ref as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _img(shape, seed=0):
+    return np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=shape, dtype=np.uint8)
+
+
+def _dev(x):
+    return torch.as_tensor(x, device="cuda")
+
+
+def _eq(out, ref, what=""):
+    got = out.cpu().numpy()
+    assert got.dtype == np.uint8 and got.shape == ref.shape
+    diff = got != ref
+    if diff.any():
+        bad_images = sorted(set(np.nonzero(diff)[0].tolist()))
+        raise AssertionError("%s: %d / %d bytes differ; images %s" % (what, int(diff.sum()), ref.size, bad_images[:16]))
+
+
+def _rand_decisions(g, n_slots, b, h, w, ops=None):
+    out = []
+    for _ in range(b):
+        out.append([{"op": int(g.integers(0, 16)) if ops is None else int(ops[int(g.integers(0, len(ops)))]),
+                     "negate": bool(g.uniform() < 0.5),
+                     "centers": np.array([[int(g.integers(0, h)), int(g.integers(0, w))]], dtype=np.int32)} for _ in range(n_slots)])
+    return out
+
+
+@pytest.mark.parametrize("shape,n_slots", [((48, 64, 64, 3), 2), ((7, 37, 50, 3), 3), ((5, 9, 10, 3), 2), ((3, 20, 24, 3), 1),
+                                           ((2, 1, 1, 3), 2), ((4, 3, 5, 3), 2), ((3, 256, 256, 3), 2)])
+def test_randaugment_elementwise_matches_oracle_per_image(shape, n_slots):
+    from chambers_amd import augmentations as aug
+    b, h, w, _ = shape
+    x = _img(shape, 11)
+    x[0] = (x[0] // 5) + 40                      # low dynamic range: AutoContrast / Equalize do real work
+    if b > 1:
+        x[1] = 93                                # constant image: their identity branches
+    g = np.random.Generator(np.random.PCG64(1000 + b))
+    dec = _rand_decisions(g, n_slots, b, h, w)
+    for n in range(min(b, 16)):                  # make sure every op occurs at least once in every case that has room
+        dec[n][0]["op"] = n % 16
+    layer = aug.RandAugment(n_slots, 9, elementwise=True)
+    _eq(layer(_dev(x), training=True, decisions=dec), A.rand_augment_elementwise(x, n_slots, 9, dec), "RandAugment elementwise")
+    # identity when not training (augmentation_schemes.py:204-213)
+    assert torch.equal(layer(_dev(x), training=False), _dev(x))
+
+
+def test_randaugment_elementwise_full_batch_512x224():
+    """BASELINE config 3 size: [512,224,224,3], RandAugment(2, 9), per-image decisions from seed 42."""
+    from chambers_amd import augmentations as aug
+    shape = (512, 224, 224, 3)
+    x = _img(shape, 0)
+    g = np.random.Generator(np.random.PCG64(42))
+    dec = _rand_decisions(g, 2, 512, 224, 224)
+    out = aug.RandAugment(2, 9, elementwise=True)(_dev(x), training=True, decisions=dec)
+    _eq(out, A.rand_augment_elementwise(x, 2, 9, dec), "RandAugment elementwise 512x224x224")
+
+
+def test_contrast_constant_and_signs_are_per_image():
+    """What elementwise mode changes semantically: Contrast's constant is H*W/256 of ONE image
+    (196 at 224x224; the batch-shared mode clips B*H*W/256 to 255), and the sign of a warp is drawn per image."""
+    from chambers_amd import augmentations as aug
+    shape = (4, 224, 224, 3)
+    x = _img(shape, 5)
+    dec = [[{"op": 4, "negate": False, "centers": np.zeros((1, 2), np.int32)}] for _ in range(4)]        # Contrast everywhere
+    out = aug.RandAugment(1, 9, elementwise=True)(_dev(x), training=True, decisions=dec).cpu().numpy()
+    np.testing.assert_array_equal(out, A.blend(np.full_like(x, 196), x, 9 / 10 * 1.8 + 0.1))
+    shared = aug.RandAugment(1, 9)(_dev(x), training=True, decisions=dec[0]).cpu().numpy()
+    np.testing.assert_array_equal(shared, A.blend(np.full_like(x, 255), x, 9 / 10 * 1.8 + 0.1))
+    assert (out != shared).any()
+    dec = [[{"op": 7, "negate": bool(n & 1), "centers": np.zeros((1, 2), np.int32)}] for n in range(4)]   # ShearX, alternating sign
+    out = aug.RandAugment(1, 9, elementwise=True)(_dev(x), training=True, decisions=dec).cpu().numpy()
+    for n in range(4):
+        np.testing.assert_array_equal(out[n:n + 1], A.projective_transform(x[n:n + 1], A.shear_x_transform(0.27, bool(n & 1)), 128))
+
+
+@pytest.mark.parametrize("shape", [(100, 64, 64, 3), (6, 33, 47, 3), (3, 224, 224, 3)])
+def test_autoaugment_elementwise_all_policies(shape):
+    from chambers_amd import augmentations as aug
+    b = shape[0]
+    x = _img(shape, 21)
+    x[0] = (x[0] // 3) + 10
+    g = np.random.Generator(np.random.PCG64(77))
+    dec = [{"policy": n % 25, "apply": (bool(g.uniform() < 0.7), bool(g.uniform() < 0.7)),
+            "negate": (bool(g.uniform() < 0.5), bool(g.uniform() < 0.5))} for n in range(b)]
+    _eq(aug.AutoAugment(elementwise=True)(_dev(x), training=True, decision=dec), A.auto_augment_elementwise(x, dec), "AutoAugment elementwise")
+
+
+def test_random_choice_elementwise_draw_order_and_generic_route():
+    """Without explicit decisions the layer draws, image by image and slot by slot, the transform index and then whatever the
+    chosen transform draws itself (sign, cutout centre): replaying the host generator reproduces the output through the
+    oracle.  A RandomChoice over layers that cannot describe themselves to the dispatch kernel takes the image-by-image route."""
+    from chambers_amd import augmentations as aug
+    from chambers_amd import rng
+    shape = (9, 32, 40, 3)
+    x = _img(shape, 31)
+    layer = aug.RandAugment(2, 9, elementwise=True)
+    rng.set_seed(123)
+    out = layer(_dev(x), training=True)
+    g = np.random.Generator(np.random.PCG64(123))
+    dec = []
+    for n in range(shape[0]):
+        ds = []
+        for _ in range(2):
+            d = {"op": int(g.integers(0, 16))}
+            name = A.RANDAUGMENT_OPS[d["op"]]
+            if name in ("ShearX", "ShearY", "TranslateX", "TranslateY", "Rotate"):
+                d["negate"] = bool(g.uniform() < 0.5)
+            if name == "CutOut":
+                d["centers"] = np.array([[int(g.integers(0, shape[1])), int(g.integers(0, shape[2]))]], dtype=np.int32)
+            ds.append(d)
+        dec.append(ds)
+    _eq(out, A.rand_augment_elementwise(x, 2, 9, dec), "drawn decisions")
+
+    choices = [[n & 1] for n in range(shape[0])]
+    ref = np.concatenate([A.invert(x[n:n + 1]) if not (n & 1) else A.solarize(x[n:n + 1], 100) for n in range(shape[0])])
+    choice = aug.RandomChoice([aug.Invert(), aug.Solarize(100)], n_transforms=1, elementwise=True)
+    _eq(choice(_dev(x), choices=choices), ref, "RandomChoice elementwise (dispatch kernel)")
+
+    from chambers_amd import kernels as K
+    from chambers_amd._keras_like import Layer
+
+    class UserInvert(Layer):          # a user-supplied layer that cannot describe itself to the dispatch kernel
+        _forward_kwargs = True
+
+        def call(self, inputs, **kwargs):
+            return K.aug_pointwise(inputs, K.PW_INVERT)
+
+    choice = aug.RandomChoice([UserInvert(), aug.Solarize(100)], n_transforms=1, elementwise=True)
+    assert not hasattr(choice.transforms[0], "dispatch_item")
+    _eq(choice(_dev(x), choices=choices), ref, "RandomChoice elementwise (image-by-image route)")
+
+
+def test_elementwise_golden_fixture():
+    import importlib.util
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden, "make_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    from chambers_amd import augmentations as aug
+    with np.load(os.path.join(golden, "augment_ops.npz")) as z:
+        ref = {k: z[k] for k in z.files}
+    for tag, shape in gen.IMAGE_SHAPES.items():
+        x = _dev(ref["x_" + tag])
+        out = aug.RandAugment(2, 9, elementwise=True)(x, training=True, decisions=gen.elementwise_randaugment_decisions(shape))
+        _eq(out, ref["randaugment_elementwise_" + tag], "golden randaugment " + tag)
+        out = aug.AutoAugment(elementwise=True)(x, training=True, decision=gen.elementwise_autoaugment_decisions(shape))
+        _eq(out, ref["autoaugment_elementwise_" + tag], "golden autoaugment " + tag)

@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from chambers_amd import kernels as K
+from chambers_amd import _lib, kernels as K
 
 B, N, H = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (512, 197, 12)
 D = H * 64
@@ -28,16 +28,16 @@ for rate in (0.0, 0.1):
     for algo in ("1", "2"):
         if algo == "1" and N > 224:
             continue
-        os.environ["CHB_ATTN_FWD_ALGO"] = algo
+        _lib.set_option("ATTN_FWD_ALGO", int(algo))
         f = t(lambda: K.attention_fwd(qkv, o, lse, B, N, H, 64, rate, 7))
         line += "   fwd[%s] %.3f ms (%.0f TF/s)" % ("resident" if algo == "1" else "stream", f, fl / f / 1e9)
     for algo, label in (("0", "default"), ("1", "resident 8 waves"), ("2", "two-pass")):
         if algo == "1" and N > 224:
             continue
-        os.environ["CHB_ATTN_BWD_ALGO"] = algo
+        _lib.set_option("ATTN_BWD_ALGO", int(algo))
         b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7))
         line += "   bwd[%s] %.3f ms (%.0f TF/s)" % (label, b, 2.5 * fl / b / 1e9)
-    os.environ["CHB_ATTN_BWD_ALGO"] = "0"
+    _lib.set_option("ATTN_BWD_ALGO", 0)
     dbias = torch.zeros(3 * D, device="cuda")
     ws = torch.empty(B * 3 * D, device="cuda")
     b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7, dbias=dbias, dbias_ws=ws))

@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from chambers_amd import kernels as K
+from chambers_amd import _lib, kernels as K
 
 M = 512 * 197
 SHAPES_NT = [("qkv_fwd", M, 2304, 768, K.EPI_NONE), ("proj_fwd", M, 768, 768, K.EPI_RESID), ("fc1_fwd", M, 3072, 768, K.EPI_GELU),
@@ -32,7 +32,7 @@ if which in ("all", "nt"):
         aux = torch.randn(m, n, device="cuda").to(torch.bfloat16) if epi in (K.EPI_GELU, K.EPI_DGELU) else None
         resid = torch.randn(m, n, device="cuda") if epi == K.EPI_RESID else None
         for walk in os.environ.get("GEMM_BENCH_WALKS", "1").split(","):
-            os.environ["CHB_GEMM_WALK"] = walk
+            _lib.set_option("GEMM_WALK", int(walk))
             ms = timeit(lambda: K.gemm_nt(a, b, out, bias=bias, epilogue=epi, aux=aux, resid=resid, drop_rate=0.1 if epi == K.EPI_RESID else 0.0, drop_key=5))
             print("%-10s M=%d N=%d K=%d epi=%d walk=%s  %.3f ms  %.1f TF/s" % (name, m, n, k, epi, walk, ms, 2.0 * m * n * k / ms / 1e9), flush=True)
 if which in ("all", "tn"):
