@@ -45,8 +45,8 @@ PROTOTYPES = {
     "chb_gemm_tn_fold": [P, c_int64, P, c_int64, c_int, c_int, c_int, P],
     "chb_layernorm_fwd": [P, c_int64, P, P, P, P, P, c_int, c_int, c_float, P],
     "chb_layernorm_bwd": [P, P, c_int64, P, P, P, P, c_int64, c_int, P, P, c_int, c_int, P, P, c_float, c_uint32, c_int, P],
-    "chb_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P],
-    "chb_attention_bwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P],
+    "chb_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P],
+    "chb_attention_bwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P, P, P],
     "chb_cls_row": [P, P, P, c_int, c_int, c_int, c_float, c_uint32, P],
     "chb_token_row": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P],
     "chb_embed_bwd": [P, P, P, P, c_int, c_int, c_int, c_float, c_uint32, P],

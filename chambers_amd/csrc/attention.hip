@@ -24,6 +24,17 @@ constexpr int HD = 64;  // head dim (all ViT configs of the reference use 64)
 
 __device__ __forceinline__ int swz_row(int r) { return (r >> 1) & 7; }          // row reads (ds_read_b128)
 __device__ __forceinline__ int swz_trv(int r) { return ((r >> 1) & 3) << 1; }   // V image, transposed reads only
+// images read BOTH ways (row fragments by ds_read_b128, transposed fragments by ds_read_b64_tr_b16): one 16-byte-chunk permutation
+// that is conflict-free for the row reads (the 8 same-parity rows of a 16-lane-group pattern get 8 distinct chunks) and for the
+// transposed reads (the 4 same-parity rows of the 8 rows a 32-lane half touches - rows r0..r0+7, or r0..r0+3 and r0+8..r0+11 - get 4
+// distinct 32-byte chunk pairs).  v = (r >> 1) & 7 -> {0, 2, 4, 6, 5, 7, 1, 3}.
+__device__ __forceinline__ int swz_dual(int r) {
+    const int v = (r >> 1) & 7;
+    return (((v + ((v >> 2) << 1)) & 3) << 1) | (v >> 2);
+}
+__device__ __forceinline__ bf16x8_t lds_row_frag_dual(const bf16_t* img, int r, int chunk) {
+    return *reinterpret_cast<const bf16x8_t*>(img + r * 64 + ((chunk ^ swz_dual(r)) << 3));
+}
 
 // row fragment: 8 consecutive d of row r, chunk index `chunk` (0..7), image swizzled with swz_row
 __device__ __forceinline__ bf16x8_t lds_row_frag(const bf16_t* img, int r, int chunk) {
@@ -41,6 +52,18 @@ __device__ __forceinline__ bf16x8_t lds_tr_frag(const bf16_t* img, int ra, int r
     const int s1 = VSWZ ? swz_trv(r1) : swz_row(r1);
     const bf16_t* a0 = img + r0 * HD + ((chunk ^ s0) << 3) + 4 * (pp & 1);
     const bf16_t* a1 = img + r1 * HD + ((chunk ^ s1) << 3) + 4 * (pp & 1);
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a0);
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a1);
+    short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t lds_tr_frag_dual(const bf16_t* img, int ra, int rb, int c0, int i) {
+    const int q = i >> 2, pp = i & 3;
+    const int chunk = (c0 >> 3) + (pp >> 1);
+    const int r0 = ra + q, r1 = rb + q;
+    const bf16_t* a0 = img + r0 * 64 + ((chunk ^ swz_dual(r0)) << 3) + 4 * (pp & 1);
+    const bf16_t* a1 = img + r1 * 64 + ((chunk ^ swz_dual(r1)) << 3) + 4 * (pp & 1);
     const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a0);
     const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a1);
     short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -138,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const bf16_t* __restri
         const float inv = 1.0f / sum;
         const int q = q0 + i;
         if (g == 0 && q < N) lse_out[(int64_t)bh * N + q] = (mxs + log2f(sum)) * 0.69314718055994530942f;
-        const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q, N - 1)) * (uint32_t)N;   // B*H*N*N < 2^32 (checked on the host)
+        const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q, N - 1)) * (uint32_t)((N + 3) & ~3);   // row stride Np4; B*H*N*Np4 < 2^32 (host)
         // dropout on the (still unnormalised) probabilities; 1/sum and 1/(1-rate) are applied to O (16 values) instead
         if (DROP) {
 #pragma unroll
@@ -179,6 +202,195 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const bf16_t* __restri
                 w.y = pack_bf16x2(oacc[dt][2] * oscale, oacc[dt][3] * oscale);
                 *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward, whole head per workgroup
+// N <= 256.  One workgroup = one (image, head): K and V of the head are brought into LDS ONCE by LDS-DMA (global_load_lds, no
+// register round trip; the bank swizzle is applied to the per-lane SOURCE chunk) and the waves then run without any further
+// barrier: wave w owns the 16-query tiles w, w + NW, ... (NW = ceil(tiles / 2): 7 waves for 197 tokens, so three workgroups
+// share a CU - 160 KiB of LDS, 21 waves - and one's load phase runs under the others' arithmetic).  A query tile walks the keys in
+// chunks of 64 with an online softmax (scores of 4 key tiles in 16 registers); key tiles past N cost nothing (wave-uniform
+// skips).  Dropout: element index ((b*H+h)*N + q)*Np4 + k with the row stride Np4 = N rounded up to 4, so the 4 consecutive keys
+// a lane holds per tile are the four 16-bit halves of exactly TWO hashes; the keep bits are also written out (8 bytes per
+// query and lane group: drop_bits[((bh*N + q)*4 + g)*2 + (t >> 3)], bit 16*(r&1) + 8*(r>>1) + (t & 7) for key 16*t + 4*g + r) so that the
+// backward pass tests a bit instead of hashing again.
+// halves of x that are >= thr (both 16-bit, unsigned): bit 0 / bit 16 of the result.  x - (thr - 1) saturating at 0 is nonzero
+// exactly for those halves; min(.., 1) makes it a flag.
+__device__ __forceinline__ uint32_t chb_pk_ge_u16(uint32_t x, uint32_t thr) {
+    const uint32_t tm1 = (thr - 1u) * 0x10001u;   // thr >= 1 (dropout rate > 0)
+    uint32_t d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(d) : "v"(x), "v"(tm1));
+    return d;
+}
+
+__device__ __forceinline__ void glds16_attn(const bf16_t* src, bf16_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+struct FwdState {
+    float& m_run;
+    float& l_run;
+    float4_t (&oacc)[4];
+    uint32_t& bits_lo;
+    uint32_t& bits_hi;
+};
+
+// one chunk (key tiles 4kc .. 4kc + nlive - 1) of one 16-query tile: scores, online-softmax update, dropout, P.V
+template <bool FULL, bool DROP>
+__device__ __forceinline__ void fwd_chunk(FwdState& st, const bf16_t* Ks, const bf16_t* Vs, const bf16x8_t& qf0, const bf16x8_t& qf1, int kc,
+                                          int nlive, int N, int g, int i, uint32_t cbase, float scale_log2, uint32_t drop_thr,
+                                          uint32_t drop_key) {
+    float4_t s[4];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        const int t = 4 * kc + tl;
+        s[tl] = (float4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (FULL || tl < nlive) {   // wave-uniform
+            s[tl] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            s[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, g), qf0, s[tl], 0, 0, 0);
+            s[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 + g), qf1, s[tl], 0, 0, 0);
+            if (!FULL && 16 * t + 16 > N) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[tl][r] = (16 * t + 4 * g + r < N) ? s[tl][r] : -INFINITY;
+            }
+            cmax = fmaxf(cmax, fmaxf(fmaxf(s[tl][0], s[tl][1]), fmaxf(s[tl][2], s[tl][3])));
+        }
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+    const float m_new = fmaxf(st.m_run, cmax);           // finite: every chunk holds at least one valid key
+    const float corr = __builtin_amdgcn_exp2f((st.m_run - m_new) * scale_log2);   // first chunk: exp2(-inf) = 0
+    st.m_run = m_new;
+    const float mxs = m_new * scale_log2;
+    st.l_run *= corr;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st.oacc[dt] *= corr;
+    // exponentials and the row sum (before dropout); dropout flags of a tile: the two 16-bit halves of a hash are compared at
+    // once (chb_pk_ge_u16: bit 0 / 16), tile tl of the chunk at bit tl of each byte lane (0, 16, 8, 24 <-> r = 0..3).
+    // Dead tiles of the last chunk are skipped (wave-uniform) and contribute exact zeros.
+    uint32_t nib4 = 0u, fl[4][2];
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        fl[tl][0] = fl[tl][1] = 0u;
+        if (FULL || tl < nlive) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[tl][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tl][r], scale_log2, -mxs));
+                st.l_run += s[tl][r];
+            }
+            if (DROP) {
+                const uint32_t c0 = cbase + 8u * (uint32_t)(4 * kc + tl);
+                const uint32_t h0 = chb_hash32(c0 ^ drop_key), h1 = chb_hash32((c0 + 1u) ^ drop_key);
+                fl[tl][0] = chb_pk_ge_u16(h0, drop_thr);
+                fl[tl][1] = chb_pk_ge_u16(h1, drop_thr);
+                nib4 |= (fl[tl][0] | (fl[tl][1] << 8)) << tl;
+            }
+        } else {
+            s[tl] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // P^T fragments of the two key-tile pairs, bf16; the dropout mask is applied to the packed pairs (flag * 0xffff per half)
+    uint4 pw[2];
+#pragma unroll
+    for (int ul = 0; ul < 2; ++ul) pw[ul] = __builtin_bit_cast(uint4, pack8(s[2 * ul], s[2 * ul + 1]));
+    if (DROP) {
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            uint32_t* w = &pw[tl >> 1].x + 2 * (tl & 1);
+            w[0] &= fl[tl][0] * 0xffffu;
+            w[1] &= fl[tl][1] * 0xffffu;
+        }
+        if (kc & 2) st.bits_hi |= nib4 << (4 * (kc & 1));   // wave-uniform
+        else st.bits_lo |= nib4 << (4 * (kc & 1));
+    }
+    // O^T[d][q] += V^T[d][key] P^T[key][q]; k-slot (g, j): j<4 -> key 32u+4g+j, j>=4 -> key 32u+16+4g+(j-4)
+#pragma unroll
+    for (int ul = 0; ul < 2; ++ul) {
+        const int u = 2 * kc + ul;
+        if (FULL || 2 * ul < nlive) {   // wave-uniform; the second tile of the last pair may be dead: its P is 0, read a live V tile
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw[ul]);
+            const int rb = (FULL || 2 * ul + 1 < nlive) ? 32 * u + 16 + 4 * g : 32 * u + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t vf = lds_tr_frag<true>(Vs, 32 * u + 4 * g, rb, 16 * dt, i);
+                st.oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, st.oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <bool DROP>
+__global__ void __launch_bounds__(512, 4) attn_fwd_head_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse_out,
+                                                            uint32_t* __restrict__ bits_out, int N, int H, int Np4, float scale_log2,
+                                                            float drop_scale, uint32_t drop_thr, uint32_t drop_key) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int nkt = (N + 15) >> 4;                 // live key tiles == query tiles
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Vs = Ks + nkt * 16 * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const bf16_t* base = qkv + (int64_t)b * N * D3 + h * HD;
+
+    // K / V images: one LDS-DMA instruction = 8 rows x 128 bytes; rows >= N re-read row N-1 (finite data; their scores are masked
+    // and their probabilities are exactly 0)
+    {
+        const int r8 = lane >> 3, c = lane & 7;
+        const int ninst = nkt * 2;
+        for (int inst = wave; inst < ninst; inst += NW) {
+            const int r = inst * 8 + r8;
+            const int rs = min(r, N - 1);
+            const bf16_t* kp = base + (int64_t)rs * D3 + Dm;
+            glds16_attn(kp + ((c ^ swz_row(r)) << 3), Ks + inst * 512);
+            glds16_attn(kp + Dm + ((c ^ swz_trv(r)) << 3), Vs + inst * 512);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int qt = wave; qt < nkt; qt += NW) {
+        const int q0 = qt * 16;
+        const int q = q0 + i, qc = min(q, N - 1);
+        const bf16_t* qp = base + (int64_t)qc * D3;
+        const bf16x8_t qf0 = *reinterpret_cast<const bf16x8_t*>(qp + g * 8);
+        const bf16x8_t qf1 = *reinterpret_cast<const bf16x8_t*>(qp + 32 + g * 8);
+        // hash counter of this lane's first key pair in tile 0: ((row * Np4) + 4g) / 2; tile t adds 8t
+        const uint32_t cbase = ((((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)Np4) >> 1) + 2u * (uint32_t)g;
+        float m_run = -INFINITY, l_run = 0.f;
+        float4_t oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        uint32_t bits_lo = 0u, bits_hi = 0u;
+        // chunks of 4 key tiles whose 64 keys all exist run a branch-free body (FULL: no liveness tests, no key mask); the last
+        // chunk of the row takes the general body with its wave-uniform tile count
+        const int nfull = N >> 6;
+        const int nchunk = (nkt + 3) >> 2;
+        FwdState st{m_run, l_run, oacc, bits_lo, bits_hi};
+#pragma unroll 1
+        for (int kc = 0; kc < nfull; ++kc)
+            fwd_chunk<true, DROP>(st, Ks, Vs, qf0, qf1, kc, 4, N, g, i, cbase, scale_log2, drop_thr, drop_key);
+        if (nfull < nchunk) fwd_chunk<false, DROP>(st, Ks, Vs, qf0, qf1, nfull, nkt - 4 * nfull, N, g, i, cbase, scale_log2, drop_thr, drop_key);
+        float sum = l_run;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float oscale = (DROP ? drop_scale : 1.0f) / sum;
+        if (q < N) {
+            if (g == 0) lse_out[(int64_t)bh * N + q] = (m_run * scale_log2 + log2f(sum)) * 0.69314718055994530942f;
+            bf16_t* op = o + ((int64_t)b * N + q) * Dm + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 w;
+                w.x = pack_bf16x2(oacc[dt][0] * oscale, oacc[dt][1] * oscale);
+                w.y = pack_bf16x2(oacc[dt][2] * oscale, oacc[dt][3] * oscale);
+                *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
+            }
+            if (DROP && bits_out) *reinterpret_cast<uint2*>(bits_out + (((int64_t)bh * N + q) * 4 + g) * 2) = make_uint2(bits_lo, bits_hi);
         }
     }
 }
@@ -296,8 +508,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
         // past N need no clamp: their probabilities are exactly zero (lse = +inf / key mask), whatever the mask bit says.
         uint32_t erow[2][4];
         {
-            const uint32_t e0 = ((uint32_t)bh * (uint32_t)N + (uint32_t)(q0 + 4 * g)) * (uint32_t)N;
-            const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane(N);
+            const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((N + 3) & ~3);   // row stride Np4 of the mask index
+            const uint32_t e0 = ((uint32_t)bh * (uint32_t)N + (uint32_t)(q0 + 4 * g)) * un;
             erow[0][0] = e0;
             erow[0][1] = erow[0][0] + un;
             erow[0][2] = erow[0][1] + un;
@@ -480,6 +692,281 @@ __device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
     return d;
 }
 
+// ------------------------------------------------------------------------------------ backward, lean one-pass kernel
+// Same decomposition as attn_bwd_kernel with NW = 16 (wave w owns key tile w and keeps its K / V fragments and dK^T / dV^T in
+// registers; dS crosses LDS once for dQ), rebuilt around the instruction count, which is what bounds it (PMC: the four waves of a
+// SIMD issue ~76 % of the cycles, three quarters of that vector ALU):
+//  * the dropout keep bits come from the forward pass (attn_fwd_head_kernel) instead of one hash per element: the head's bit rows
+//    sit in LDS, a lane reads one word per query row and tests one lane-constant bit;
+//  * key tiles and query sub-tiles that lie entirely past N are skipped (N = 197: 3 of 16 waves and half of the last query block);
+//    the waves without a key tile are the ones that form dQ (phase B), off the critical path of the others;
+//  * Q, dO and K images use one swizzle that is conflict-free for the row reads (ds_read_b128) AND for both transposed-read
+//    patterns (swz_dual); dS is written transposed, [key][32 queries], as two 8-byte stores per tile instead of eight 2-byte ones,
+//    with a piece / slot rotation that keeps those stores and the transposed reads of phase B conflict-free;
+//  * 1/sqrt(hd) = 2^-3 is exact in bf16, so it multiplies dQ and dK when they are stored instead of every dS element;
+//  * Q and K arrive by LDS-DMA, V and K fragments straight from global memory (the V image is gone: 28 KiB less LDS);
+//    lse / delta are read as float4.
+// workgroup barrier that orders LDS traffic only: every LDS operation of this wave has completed (lgkmcnt(0)), global stores and
+// LDS-DMA stay in flight across it (__syncthreads() also waits vmcnt(0): a dQ store issued right before it would put the store's
+// round trip to HBM on the critical path of every step)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+
+template <int NTP>
+constexpr size_t bwd_head_lds_bytes() {
+    return (size_t)(3 * 32 * NTP * HD + 2 * 32 * NTP * 32) * sizeof(bf16_t) + (size_t)2 * 32 * NTP * sizeof(float) + (size_t)32 * NTP * 10 * sizeof(uint32_t);
+}
+
+// byte offset inside one dS^T buffer of the 8-byte slot holding queries 16*qs + 4*gq .. +3 of key row `key`
+__device__ __forceinline__ int dst_slot(int key, int qs, int gq) {
+    return key * 64 + ((qs ^ ((key >> 3) & 1)) << 5) + (((gq + (key >> 1)) & 3) << 3);
+}
+
+template <int NTP, bool DROP, bool BITS>
+__global__ void __launch_bounds__(1024, 4) attn_bwd_head_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                             const uint32_t* __restrict__ drop_bits, int N, int H, float scale,
+                                                             float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key, int dbg) {
+    constexpr int NP = 32 * NTP, NTHR = 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Qs = Ks + NP * HD;
+    bf16_t* Gs = Qs + NP * HD;                      // dO
+    char* dST = reinterpret_cast<char*>(Gs + NP * HD);                  // [2][NP keys][64 bytes]
+    float* lse2 = reinterpret_cast<float*>(dST + 2 * NP * 64);
+    float* delta = lse2 + NP;
+    uint32_t* bitsL = reinterpret_cast<uint32_t*>(delta + NP);         // [NP queries][10]: 4 g x 2 halves + 2 pad words (a lane group reads
+                                                                       // rows 4 apart: 40 words, so the four groups use disjoint banks)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const bf16_t* base = qkv + (int64_t)b * N * D3 + h * HD;
+    const bf16_t* obase = o + (int64_t)b * N * Dm + h * HD;
+    const bf16_t* gbase = d_o + (int64_t)b * N * Dm + h * HD;
+    const int nkt = (N + 15) >> 4;                  // live 16-key tiles
+    const int nqb = dbg == 1 ? 0 : (N + 31) >> 5;   // live 32-query blocks (dbg = 1: timing build of prologue + epilogue alone)
+    const int t = wave;                             // this wave's key tile
+    const bool tile_live = t < nkt;                 // wave-uniform
+    const int key = 16 * t + i;
+
+    // ---- prologue: Q and K images by LDS-DMA (rows >= N re-read row N-1: finite, and every use of them is masked)
+    {
+        const int r8 = lane >> 3, c = lane & 7;
+        for (int inst = wave; inst < NP / 8; inst += 16) {
+            const int r = inst * 8 + r8;
+            const bf16_t* src = base + (int64_t)min(r, N - 1) * D3 + ((c ^ swz_dual(r)) << 3);
+            glds16_attn(src, Qs + inst * 512);
+            glds16_attn(src + Dm, Ks + inst * 512);
+        }
+    }
+    // this wave's K / V row fragments (B operands of S and dP) straight from global memory
+    bf16x8_t kfr[2], vfr[2];
+    {
+        const bf16_t* kp = base + (int64_t)min(key, N - 1) * D3 + Dm;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kfr[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 32 * ks + 8 * g);
+            vfr[ks] = *reinterpret_cast<const bf16x8_t*>(kp + Dm + 32 * ks + 8 * g);
+        }
+    }
+    // dO image + delta[q] = sum_d dO*O (8 threads per row, one 16-byte chunk each); rows >= N are zero
+    for (int id = tid; id < ((NP * 8 + NTHR - 1) & ~(NTHR - 1)); id += NTHR) {
+        const int r = id >> 3, c = id & 7;
+        uint4 gv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+        if (r < N && r < NP) {
+            gv = *reinterpret_cast<const uint4*>(gbase + (int64_t)r * Dm + c * 8);
+            ov = *reinterpret_cast<const uint4*>(obase + (int64_t)r * Dm + c * 8);
+        }
+        if (r < NP) *reinterpret_cast<uint4*>(Gs + r * HD + ((c ^ swz_dual(r)) << 3)) = gv;
+        float d = dot8_bf16(gv, ov);
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (c == 0 && r < NP) delta[r] = d;
+    }
+    for (int r = tid; r < NP; r += NTHR) lse2[r] = r < N ? lse[(int64_t)bh * N + r] * 1.44269504088896340736f : INFINITY;
+    if (BITS) {
+        const uint32_t* src = drop_bits + (int64_t)bh * N * 8;
+        for (int id = tid; id < NP * 8; id += NTHR) bitsL[(id >> 3) * 10 + (id & 7)] = id < N * 8 ? src[id] : 0u;
+    }
+    for (int id = tid; id < 2 * NP * 4; id += NTHR) reinterpret_cast<uint4*>(dST)[id] = make_uint4(0, 0, 0, 0);   // rows of dead key tiles stay 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float4_t dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        dk[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        dv[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // lane-constant LDS offsets (query blocks start at multiples of 32, so every swizzle depends on the lane only)
+    const int lq = i >> 2, lpp = i & 3;
+    int rowoff[2];            // row fragments of Q / dO: row (16 qs) + i, chunk 4 ks + g
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) rowoff[ks] = i * HD + (((4 * ks + g) ^ swz_dual(i)) << 3);
+    int troff[4];             // transposed fragments of Q / dO: rows 4g + lq (and + 16), columns 16 dt + 4 lpp ..
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) troff[dt] = (4 * g + lq) * HD + (((2 * dt + (lpp >> 1)) ^ swz_dual(4 * g + lq)) << 3) + 4 * (lpp & 1);
+    const int dst_w0 = dst_slot(key, 0, g), dst_w1 = dst_slot(key, 1, g);     // this lane's two dS^T stores (key row, query groups g / 4+g)
+    const int bit_off = (4 * g) * 10 + (i >> 2) * 2 + (t >> 3);               // word of query row 4g (+ r*10) for this lane's key
+    const int bit_pos = 16 * (i & 1) + 8 * ((i >> 1) & 1) + (t & 7);
+    const uint32_t dsc_bits = __float_as_uint(drop_scale);
+    // keys >= N of the partial tile: the score chain starts from -inf instead of 0, so p = exp2(-inf) = 0 without a select
+    const float s0 = key < N ? 0.f : -INFINITY;
+    const float4_t sinit = (float4_t){s0, s0, s0, s0};
+    // Roles are fixed for the whole kernel and exclusive (N <= 224: at least two of the 16 waves own no live key tile): the waves
+    // with a key tile run phase A of block `it`, the others form dQ of block it - 1 (phase B) from the dS^T tile published one
+    // round earlier, between the same pair of barriers.  Two separate loops, so the register allocation of one role does not
+    // carry the other's live state (dK / dV accumulators and K / V fragments on one side, 14 prefetched fragments on the other).
+    const int nwork = 16 - nkt;
+    const int widx = wave - nkt;
+    // phase-B fragment addresses = lane constant + 32u rows: K^T rows 8g + lq (+4), d columns 16dt + 4lpp ..; dS^T rows likewise,
+    // query columns 16qs + 4lpp .. (swizzle / piece / slot of row 32u + r equal those of row r)
+    const int kra = 8 * g + lq, krb = kra + 4;
+    int kboff[4][2], sboff[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        kboff[dt][0] = (kra * HD + (((2 * dt + (lpp >> 1)) ^ swz_dual(kra)) << 3) + 4 * (lpp & 1)) * 2;
+        kboff[dt][1] = (krb * HD + (((2 * dt + (lpp >> 1)) ^ swz_dual(krb)) << 3) + 4 * (lpp & 1)) * 2;
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        sboff[qs][0] = dst_slot(kra, qs, lpp);
+        sboff[qs][1] = dst_slot(krb, qs, lpp);
+    }
+    if (tile_live) {
+        for (int it = 0; it <= nqb; ++it) {
+            const int q0 = 32 * it;
+            if (it < nqb) {
+                // ---- phase A: this wave's 16 keys against the (up to) 32 queries of the block
+                char* dSb = dST + (it & 1) * NP * 64;
+                const bool two = q0 + 16 < N;                         // second 16-query sub-tile has live queries (wave-uniform)
+                float4_t pd[2], ds[2];
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    pd[qs] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    ds[qs] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    if (qs == 0 || two) {
+                        const bf16_t* qrow = Qs + (q0 + 16 * qs) * HD;
+                        const bf16_t* grow = Gs + (q0 + 16 * qs) * HD;
+                        const float4_t l2 = *reinterpret_cast<const float4_t*>(lse2 + q0 + 16 * qs + 4 * g);
+                        const float4_t dl = *reinterpret_cast<const float4_t*>(delta + q0 + 16 * qs + 4 * g);
+                        uint32_t bw[4] = {0u, 0u, 0u, 0u};
+                        if (BITS) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bw[r] = bitsL[(q0 + 16 * qs + r) * 10 + bit_off];
+                        }
+                        float4_t sv = sinit, dp = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            // D[row = query 4g+r][col = key i]
+                            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(qrow + rowoff[ks]), kfr[ks], sv, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(grow + rowoff[ks]), vfr[ks], dp, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], scale_log2, -l2[r]));    // pad queries: lse = +inf -> 0
+                            float keepc = 1.0f;
+                            if (DROP) {
+                                if (BITS) {
+                                    const int32_t m = __builtin_amdgcn_sbfe((int32_t)bw[r], bit_pos, 1);      // 0 or -1
+                                    keepc = __uint_as_float((uint32_t)m & dsc_bits);
+                                } else {
+                                    const uint32_t e = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + 16 * qs + 4 * g + r, N - 1)) * (uint32_t)((N + 3) & ~3) +
+                                                       (uint32_t)min(key, N - 1);
+                                    const uint32_t hsh = chb_hash32((e >> 1) ^ drop_key);
+                                    const uint32_t u = (e & 1u) ? (hsh >> 16) : (hsh & 0xffffu);
+                                    keepc = (u >= drop_thr) ? drop_scale : 0.f;
+                                }
+                            }
+                            pd[qs][r] = p * keepc;                                  // dropped probabilities (for dV)
+                            ds[qs][r] = p * __builtin_fmaf(dp[r], keepc, -dl[r]);   // d(scores) * sqrt(hd): 2^-3 goes onto dQ / dK at the store
+                        }
+                    }
+                }
+                // contraction over the 32 queries: k-slot (g, j): j<4 -> q0+4g+j, j>=4 -> q0+16+4g+(j-4)
+                const bf16x8_t pf = pack8(pd[0], pd[1]);
+                const bf16x8_t sf = pack8(ds[0], ds[1]);
+                const bf16_t* gt0 = Gs + q0 * HD;
+                const bf16_t* qt0 = Qs + q0 * HD;
+                const int second = two ? 16 * HD : 0;       // dead second sub-tile: its P / dS are 0, read the live rows again
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8_t gt = lds_tr_frag_at(gt0 + troff[dt], gt0 + second + troff[dt]);
+                    const bf16x8_t qt = lds_tr_frag_at(qt0 + troff[dt], qt0 + second + troff[dt]);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dv[dt], 0, 0, 0);  // dV^T[d][key]
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sf, dk[dt], 0, 0, 0);  // dK^T[d][key]
+                }
+                // dS^T tile -> LDS [key][query]: the packed fragment IS the two 8-byte rows (queries 4g.., 16+4g..)
+                const uint4 sw = __builtin_bit_cast(uint4, sf);
+                *reinterpret_cast<uint2*>(dSb + dst_w0) = make_uint2(sw.x, sw.y);
+                *reinterpret_cast<uint2*>(dSb + dst_w1) = make_uint2(sw.z, sw.w);
+            }
+            lds_barrier();   // dS^T of block `it` is published; buffer (it - 1) & 1 is free for block it + 1
+        }
+    } else {
+        for (int it = 0; it <= nqb; ++it) {
+            // ---- phase B (block it - 1): dQ[q][d] = sum_key dS[q][key] K[key][d], one 16 x 16 tile (qs, dt) per task
+            if (it > 0) {
+                const int qb0 = 32 * (it - 1);
+                const char* dSb = dST + ((it - 1) & 1) * NP * 64;
+                for (int task = widx; task < 8; task += nwork) {
+                    const int qs = task >> 2, dtw = task & 3;
+                    if (qb0 + 16 * qs < N) {   // wave-uniform
+                        // A[row d][k = key 32u+8g+j] = K^T: transposed read of the K image; B[k = key][col = query] = dS^T: transposed read
+                        // of the [key][query] image (lane 4q'+p supplies row 8g+q' (+4), queries 16qs + 4p ..).  All fragment reads of the
+                        // task are issued before its MFMA chain (compile-time trip count: pairs past the last live tile read zero dS rows).
+                        bf16x8_t kt[NTP], sb[NTP];
+                        const char* kp0 = reinterpret_cast<const char*>(Ks) + (dtw == 0 ? kboff[0][0] : dtw == 1 ? kboff[1][0] : dtw == 2 ? kboff[2][0] : kboff[3][0]);
+                        const char* kp1 = reinterpret_cast<const char*>(Ks) + (dtw == 0 ? kboff[0][1] : dtw == 1 ? kboff[1][1] : dtw == 2 ? kboff[2][1] : kboff[3][1]);
+                        const char* sp0 = dSb + (qs ? sboff[1][0] : sboff[0][0]);
+                        const char* sp1 = dSb + (qs ? sboff[1][1] : sboff[0][1]);
+#pragma unroll
+                        for (int u = 0; u < NTP; ++u) {
+                            kt[u] = lds_tr_frag_at(reinterpret_cast<const bf16_t*>(kp0 + u * 32 * HD * 2), reinterpret_cast<const bf16_t*>(kp1 + u * 32 * HD * 2));
+                            sb[u] = lds_tr_frag_at(reinterpret_cast<const bf16_t*>(sp0 + u * 32 * 64), reinterpret_cast<const bf16_t*>(sp1 + u * 32 * 64));
+                        }
+                        float4_t dq = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int u = 0; u < NTP; ++u) dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[u], sb[u], dq, 0, 0, 0);
+                        // D[row = d 4g+r][col = query i]
+                        const int q = qb0 + 16 * qs + i;
+                        if (q < N) {
+                            uint2 w;
+                            w.x = pack_bf16x2(dq[0] * scale, dq[1] * scale);
+                            w.y = pack_bf16x2(dq[2] * scale, dq[3] * scale);
+                            *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * dtw + 4 * g) = w;
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+    }
+    // dK^T / dV^T accumulators: lane (g,i) reg r = [d = 16dt + 4g + r][key = 16t + i]
+    if (tile_live && key < N) {
+        bf16_t* kp = dqkv + ((int64_t)b * N + key) * D3 + Dm + h * HD;
+        bf16_t* vp = kp + Dm;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 w;
+            w.x = pack_bf16x2(dk[dt][0] * scale, dk[dt][1] * scale);
+            w.y = pack_bf16x2(dk[dt][2] * scale, dk[dt][3] * scale);
+            *reinterpret_cast<uint2*>(kp + 16 * dt + 4 * g) = w;
+            w.x = pack_bf16x2(dv[dt][0], dv[dt][1]);
+            w.y = pack_bf16x2(dv[dt][2], dv[dt][3]);
+            *reinterpret_cast<uint2*>(vp + 16 * dt + 4 * g) = w;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ forward, long sequences
 // N > 224: the score row of a query no longer fits the register file next to K/V in LDS.  Workgroup = (head, 128
 // queries), a wave owns 16 queries; K / V stream through a double-buffered LDS chunk of 64 keys and the softmax is
@@ -507,7 +994,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_stream_kernel(const bf16_t* _
     const bf16_t* qp = base + (int64_t)qc * D3;
     const bf16x8_t qf0 = *reinterpret_cast<const bf16x8_t*>(qp + g * 8);
     const bf16x8_t qf1 = *reinterpret_cast<const bf16x8_t*>(qp + 32 + g * 8);
-    const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)N;
+    const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)((N + 3) & ~3);
 
     float m_run = -INFINITY;   // running max of the raw scores of this query (identical in the 4 lanes g of a query)
     float l_run = 0.f;         // this lane's share of the running sum (keys 4g+r of every tile)
@@ -677,7 +1164,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __re
         }
     };
     auto stage_store = [&](int buf) {
-        bf16_t* dst = (role_g ? Gb[buf] : Qb[buf]) + sr * HD + ((sc ^ swz_row(sr)) << 3);
+        bf16_t* dst = (role_g ? Gb[buf] : Qb[buf]) + sr * HD + ((sc ^ swz_dual(sr)) << 3);
         *reinterpret_cast<uint4*>(dst) = sv0;
         if (role_g) {
             float d = dot8_bf16(sv0, sv1);
@@ -707,8 +1194,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     // D[row = query 4g+r][col = key i]
-                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Qs, 16 * qs + i, 4 * ks + g), kfr[ks], sv, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Gs, 16 * qs + i, 4 * ks + g), vfr[ks], dp, 0, 0, 0);
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag_dual(Qs, 16 * qs + i, 4 * ks + g), kfr[ks], sv, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag_dual(Gs, 16 * qs + i, 4 * ks + g), vfr[ks], dp, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -717,7 +1204,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __re
                     if (!tile_full) p = (key < N) ? p : 0.f;
                     float keepc = 1.0f;
                     if (DROP) {
-                        const uint32_t e = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + ql, N - 1)) * (uint32_t)N + (uint32_t)min(key, N - 1);
+                        const uint32_t e = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + ql, N - 1)) * (uint32_t)((N + 3) & ~3) + (uint32_t)min(key, N - 1);
                         const uint32_t hsh = chb_hash32((e >> 1) ^ drop_key);
                         const uint32_t u = (e & 1u) ? (hsh >> 16) : (hsh & 0xffffu);
                         keepc = (u >= drop_thr) ? drop_scale : 0.f;
@@ -731,8 +1218,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __re
             const bf16x8_t sf = pack8(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8_t gt = lds_tr_frag<false>(Gs, 4 * g, 16 + 4 * g, 16 * dt, i);
-                const bf16x8_t qt = lds_tr_frag<false>(Qs, 4 * g, 16 + 4 * g, 16 * dt, i);
+                const bf16x8_t gt = lds_tr_frag_dual(Gs, 4 * g, 16 + 4 * g, 16 * dt, i);
+                const bf16x8_t qt = lds_tr_frag_dual(Qs, 4 * g, 16 + 4 * g, 16 * dt, i);
                 dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dv[dt], 0, 0, 0);  // dV^T[d][key]
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sf, dk[dt], 0, 0, 0);  // dK^T[d][key]
             }
@@ -811,7 +1298,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(const bf16_t* __res
         dl += __shfl_xor(dl, 32, 64);
     }
     const float l2 = lse[(int64_t)bh * N + qc] * 1.44269504088896340736f;
-    const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)N;
+    const uint32_t ebase = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)((N + 3) & ~3);
 
     float4_t dq[4];
 #pragma unroll
@@ -830,7 +1317,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(const bf16_t* __res
         }
     };
     auto stage_store = [&](int buf) {
-        const int off = sr * HD + ((sc ^ swz_row(sr)) << 3);
+        const int off = sr * HD + ((sc ^ swz_dual(sr)) << 3);
         *reinterpret_cast<uint4*>(Kb[buf] + off) = skv;
         *reinterpret_cast<uint4*>(Vb[buf] + off) = svv;
     };
@@ -857,8 +1344,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             // D[row = key 4g+r][col = query i]
-                            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qb[ks], sv, 0, 0, 0);
-                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Vs, 16 * t + i, 4 * ks + g), gb[ks], dp, 0, 0, 0);
+                            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag_dual(Ks, 16 * t + i, 4 * ks + g), qb[ks], sv, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag_dual(Vs, 16 * t + i, 4 * ks + g), gb[ks], dp, 0, 0, 0);
                         }
                         float keepc[4] = {1.f, 1.f, 1.f, 1.f};
                         if (DROP) keep4(ebase + (uint32_t)key0, drop_key, drop_thr, drop_scale, keepc);
@@ -874,7 +1361,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(const bf16_t* __res
                     const bf16x8_t sf = pack8(ds[0], ds[1]);
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
-                        const bf16x8_t kt = lds_tr_frag<false>(Ks, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, i);
+                        const bf16x8_t kt = lds_tr_frag_dual(Ks, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, i);
                         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, sf, dq[dt], 0, 0, 0);
                     }
                 }
@@ -926,10 +1413,10 @@ __global__ void __launch_bounds__(256) dbias_reduce_kernel(const float* __restri
 extern "C" {
 
 int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate, uint32_t drop_key,
-                      void* stream) {
+                      uint32_t* drop_bits, void* stream) {
     if (!qkv || !o || !lse || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
     if (hd != HD) return CHB_EUNSUPPORTED;
-    if ((double)B * H * N * N >= 4294967296.0) return CHB_EUNSUPPORTED;   // dropout element index is 32-bit
+    if ((double)B * H * N * ((N + 3) & ~3) >= 4294967296.0) return CHB_EUNSUPPORTED;   // dropout element index is 32-bit
     if (B == 0) return CHB_OK;
     const float scale_log2 = 1.44269504088896340736f / sqrtf((float)hd);
     const float ds = 1.0f / (1.0f - drop_rate);
@@ -942,6 +1429,25 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
     // kernel with online softmax (any N; at N = 197 it runs 4 waves per SIMD against 2 and measures ~10 % faster).
     // CHB_ATTN_FWD_ALGO = 1 | 2 forces resident (N <= 224) | streaming; the parity tests cross-check the two.
     const int algo = chb_option(CHB_OPT_ATTN_FWD_ALGO);
+    // default for N <= 224: the whole-head kernel (K / V in LDS once, online softmax, two hashes per four keys, keep bits saved for
+    // the backward).  CHB_ATTN_FWD_ALGO = 1 | 2 forces the resident (N <= 224) | streaming kernel: the parity tests cross-check.
+    if (N <= 224 && algo != 1 && algo != 2) {
+        const int nkt = (N + 15) >> 4;
+        const int nw = (nkt + 1) >> 1;
+        const size_t lds = (size_t)2 * nkt * 16 * HD * sizeof(bf16_t);
+        static std::atomic<bool> attr_set{false};
+        if (!attr_set.load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute((const void*)attn_fwd_head_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_fwd_head_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+                return CHB_ELAUNCH;
+            attr_set.store(true, std::memory_order_release);
+        }
+        const int np4 = (N + 3) & ~3;
+        if (thr) hipLaunchKernelGGL((attn_fwd_head_kernel<true>), grid, dim3(64 * nw), lds, s, in, out, lse, drop_bits, N, H, np4, scale_log2, ds, thr, drop_key);
+        else hipLaunchKernelGGL((attn_fwd_head_kernel<false>), grid, dim3(64 * nw), lds, s, in, out, lse, drop_bits, N, H, np4, scale_log2, ds, thr, drop_key);
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
     if (N > 224 || algo == 2 || (algo != 1 && N > 128)) {
         const dim3 grid2(B * H, (N + 127) / 128);
         if (thr) hipLaunchKernelGGL((attn_fwd_stream_kernel<true>), grid2, dim3(512), 0, s, in, out, lse, N, H, scale_log2, ds, thr, drop_key);
@@ -964,10 +1470,10 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
 }
 
 int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N, int H, int hd,
-                      float drop_rate, uint32_t drop_key, float* dbias_qkv, float* dbias_ws, void* stream) {
+                      float drop_rate, uint32_t drop_key, float* dbias_qkv, float* dbias_ws, const uint32_t* drop_bits, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || B < 0 || N <= 0 || H <= 0 || drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
     if (hd != HD) return CHB_EUNSUPPORTED;
-    if ((double)B * H * N * N >= 4294967296.0) return CHB_EUNSUPPORTED;
+    if ((double)B * H * N * ((N + 3) & ~3) >= 4294967296.0) return CHB_EUNSUPPORTED;
     if (B == 0) return CHB_OK;
     const float scale = 1.0f / sqrtf((float)hd);
     const float scale_log2 = 1.44269504088896340736f * scale;
@@ -992,6 +1498,40 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid2, block, 0, s, a0, a1, a2, lse, out, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);
             hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid2, block, 0, s, a0, a1, a2, lse, out, N, H, scale, scale_log2, ds, thr, drop_key, dbias_qkv);
         }
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
+    // default (no fused bias gradient, CHB_ATTN_BWD_ALGO = 0): the lean kernel; it tests the forward's keep bits when they are given
+    if (!dbias_qkv && (bwd_algo == 0 || bwd_algo == 4)) {
+#define CHB_BWDH_V(NTP, DROP, BITS)                                                                                              \
+    do {                                                                                                                         \
+        const size_t lds = bwd_head_lds_bytes<NTP>();                                                                            \
+        static std::atomic<bool> attr_set{false};                                                                                \
+        if (!attr_set.load(std::memory_order_acquire)) {                                                                         \
+            if (hipFuncSetAttribute((const void*)attn_bwd_head_kernel<NTP, DROP, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                return CHB_ELAUNCH;                                                                                              \
+            attr_set.store(true, std::memory_order_release);                                                                     \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((attn_bwd_head_kernel<NTP, DROP, BITS>), grid, dim3(1024), lds, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, \
+                           lse, (bf16_t*)dqkv, drop_bits, N, H, scale, scale_log2, ds, thr, drop_key, chb_option(CHB_OPT_DEBUG));     \
+    } while (0)
+#define CHB_BWDH(NTP)                                          \
+    do {                                                       \
+        if (!thr) CHB_BWDH_V(NTP, false, false);               \
+        else if (drop_bits) CHB_BWDH_V(NTP, true, true);       \
+        else CHB_BWDH_V(NTP, true, false);                     \
+    } while (0)
+        switch ((N + 31) >> 5) {
+            case 1: CHB_BWDH(1); break;
+            case 2: CHB_BWDH(2); break;
+            case 3: CHB_BWDH(3); break;
+            case 4: CHB_BWDH(4); break;
+            case 5: CHB_BWDH(5); break;
+            case 6: CHB_BWDH(6); break;
+            default: CHB_BWDH(7); break;
+        }
+#undef CHB_BWDH
+#undef CHB_BWDH_V
         CHB_LAUNCH_CHECK();
         return CHB_OK;
     }

@@ -465,11 +465,15 @@ class ViTEngine:
         self.patches = z(self.Mpatch_p, cfg.patch_k)
         self.xs = [z(Mp, d, dtype=f32) for _ in range((L + 1) if self.training else 2)]
         self.acts = []
+        # keep bits of the dropout on the attention probabilities, written by the forward and tested by the backward (one word pair
+        # per query and lane group: 32 bytes per query row, 39 MB per block at batch 512 / 197 tokens)
+        self.use_drop_bits = self.training and cfg.dropout_rate > 0.0 and n <= 224
         for _ in range(nsave):
             self.acts.append({
                 "h1": z(Mp, d), "mean1": z(Mp, dtype=f32), "rstd1": z(Mp, dtype=f32), "qkv": z(Mp, 3 * d), "o": z(Mp, d),
                 "lse": z(B * cfg.n_heads * n, dtype=f32), "xmid": z(Mp, d, dtype=f32), "h2": z(Mp, d), "mean2": z(Mp, dtype=f32),
-                "rstd2": z(Mp, dtype=f32), "a1": z(Mp, ff), "u": z(Mp, ff)})
+                "rstd2": z(Mp, dtype=f32), "a1": z(Mp, ff), "u": z(Mp, ff),
+                "drop_bits": K.attention_drop_bits(B, n, cfg.n_heads, device=dev) if self.use_drop_bits else None})
         self.hf = z(self.Bp, d)                      # pooled, normalised embedding (bf16 operand of the heads)
         nstat = self.Bp if cfg.pooling == "cls" else Mp
         self.meanf, self.rstdf = z(nstat, dtype=f32), z(nstat, dtype=f32)
@@ -513,7 +517,7 @@ class ViTEngine:
 
     def activation_bytes(self):
         tot = 0
-        for t in [self.patches, self.hf] + self.xs + [v for a in self.acts for v in a.values()]:
+        for t in [self.patches, self.hf] + self.xs + [v for a in self.acts for v in a.values() if v is not None]:
             tot += t.numel() * t.element_size()
         return tot
 
@@ -550,7 +554,8 @@ class ViTEngine:
         K.layernorm_fwd(x_in, d, self.p(pre + "norm1/gamma"), self.p(pre + "norm1/beta"), a["h1"], a["mean1"], a["rstd1"], M, d,
                         cfg.norm_epsilon)
         K.gemm_nt(a["h1"], self.wbt(pre + "qkv/kernel"), a["qkv"], m=M, bias=self.p(pre + "qkv/bias"))
-        K.attention_fwd(a["qkv"], a["o"], a["lse"], self.B, cfg.n_tokens, cfg.n_heads, cfg.head_dim, rate, key(rng.site_attn(l)))
+        K.attention_fwd(a["qkv"], a["o"], a["lse"], self.B, cfg.n_tokens, cfg.n_heads, cfg.head_dim, rate, key(rng.site_attn(l)),
+                        drop_bits=a["drop_bits"] if rate else None)
         K.gemm_nt(a["o"], self.wbt(pre + "proj/kernel"), a["xmid"], m=M, bias=self.p(pre + "proj/bias"), epilogue=K.EPI_RESID,
                   resid=x_in, drop_rate=rate, drop_key=key(rng.site_proj(l)))
         K.layernorm_fwd(a["xmid"], d, self.p(pre + "norm2/gamma"), self.p(pre + "norm2/beta"), a["h2"], a["mean2"], a["rstd2"], M, d,
@@ -721,7 +726,7 @@ class ViTEngine:
             self.reducer.bucket_ready(2 * (L - l) - 1)
             self.reducer.flush()
             K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], self.dqkv, self.B, n, cfg.n_heads, cfg.head_dim, rate,
-                            key(rng.site_attn(l)))
+                            key(rng.site_attn(l)), drop_bits=a["drop_bits"] if rate else None)
             # the QKV bias gradient (column sums of dqkv) rides along in the weight-gradient GEMM as ones^T . dqkv: +5 % on that
             # launch instead of a 0.09 ms pass over dqkv (attention_bwd can also fuse it via dbias=, but its four extra
             # accumulators and the cross-wave fold make the 128-register kernel spill: 0.99 ms against 0.69)

@@ -335,23 +335,32 @@ def layernorm_bwd(dy, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate,
     return dx
 
 
-def attention_fwd(qkv, o, lse, b, n, h, hd, drop_rate=0.0, drop_key=0):
-    _lib.require_gpu(qkv, o, lse)
+def attention_drop_bits(b, n, h, device="cuda"):
+    """Buffer for the keep bits of one attention site (forward writes, backward reads): uint32 [B*H*N*8] (int32 storage)."""
+    return torch.empty(int(b) * int(h) * int(n) * 8, dtype=torch.int32, device=device)
+
+
+def attention_fwd(qkv, o, lse, b, n, h, hd, drop_rate=0.0, drop_key=0, drop_bits=None):
+    _lib.require_gpu(qkv, o, lse, drop_bits)
+    if drop_bits is not None and (drop_bits.dtype != torch.int32 or drop_bits.numel() < int(b) * int(h) * int(n) * 8):
+        raise ValueError("drop_bits must be int32 with at least B*H*N*8 elements")
     _lib.call("chb_attention_fwd", _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse), int(b), int(n), int(h), int(hd), float(drop_rate),
-              ctypes.c_uint32(int(drop_key)), _s())
+              ctypes.c_uint32(int(drop_key)), _lib.ptr(drop_bits), _s())
     return o
 
 
-def attention_bwd(qkv, o, d_o, lse, dqkv, b, n, h, hd, drop_rate=0.0, drop_key=0, dbias=None, dbias_ws=None):
+def attention_bwd(qkv, o, d_o, lse, dqkv, b, n, h, hd, drop_rate=0.0, drop_key=0, dbias=None, dbias_ws=None, drop_bits=None):
     """dbias (fp32 [3*h*hd]): += column sums of dqkv; dbias_ws (fp32 [b, 3*h*hd] scratch): per-head sums go there with plain
     stores and one small launch folds them (n <= 224), instead of one atomic per head and column."""
-    _lib.require_gpu(qkv, o, d_o, lse, dqkv, dbias, dbias_ws)
+    _lib.require_gpu(qkv, o, d_o, lse, dqkv, dbias, dbias_ws, drop_bits)
+    if drop_bits is not None and (drop_bits.dtype != torch.int32 or drop_bits.numel() < int(b) * int(h) * int(n) * 8):
+        raise ValueError("drop_bits must be int32 with at least B*H*N*8 elements")
     if dbias is not None and dbias_ws is None:
         dbias_ws = torch.empty(int(b) * 3 * int(h) * int(hd), dtype=torch.float32, device=dbias.device)
     if dbias_ws is not None and (dbias_ws.dtype != torch.float32 or dbias_ws.numel() < int(b) * 3 * int(h) * int(hd)):
         raise ValueError("dbias_ws must be fp32 with at least b * 3 * h * hd elements")
     _lib.call("chb_attention_bwd", _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(d_o), _lib.ptr(lse), _lib.ptr(dqkv), int(b), int(n), int(h), int(hd),
-              float(drop_rate), ctypes.c_uint32(int(drop_key)), _lib.ptr(dbias), _lib.ptr(dbias_ws), _s())
+              float(drop_rate), ctypes.c_uint32(int(drop_key)), _lib.ptr(dbias), _lib.ptr(dbias_ws), _lib.ptr(drop_bits), _s())
     return dqkv
 
 

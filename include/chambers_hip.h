@@ -166,17 +166,22 @@ int chb_layernorm_bwd(const void* dy_bf16, const float* x, int64_t x_stride, con
 
 /* MultiHeadAttention core (layers/attention.py:7-23,113-125): softmax(QK^T/sqrt(hd)) with
  * dropout on the probabilities, times V.  qkv bf16 [B*N, 3*H*hd] = [Q heads | K heads | V heads];
- * o bf16 [B*N, H*hd]; lse fp32 [B,H,N]. hd == 64; any N with B*H*N*N < 2^32 (the dropout element index
- * ((b*H+h)*N+q)*N+k is 32-bit): N <= 224 runs with the head resident in LDS, longer sequences (577 tokens at
- * 384x384) through the streaming forward and the two-pass backward. */
+ * o bf16 [B*N, H*hd]; lse fp32 [B,H,N]. hd == 64; any N with B*H*N*Np4 < 2^32, Np4 = N rounded up to a multiple of 4
+ * (the dropout element index ((b*H+h)*N+q)*Np4+k is 32-bit): N <= 224 runs with the head resident in LDS, longer
+ * sequences (577 tokens at 384x384) through the streaming forward and the two-pass backward.
+ * drop_bits (optional, uint32 [B*H*N*8], N <= 224, drop_rate > 0): the forward writes the keep bits of the mask it applied
+ * (word ((bh*N + q)*4 + g)*2 + (t >> 3), bit 16*(r&1) + 8*(r>>1) + (t & 7) for key 16*t + 4*g + r); handed to chb_attention_bwd, the
+ * backward tests bits instead of re-hashing (keras Dropout keeps its mask for the backward pass likewise).  NULL: nothing is
+ * written / the backward regenerates the mask from the element index.  Same results either way. */
 int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate,
-                      uint32_t drop_key, void* stream);
+                      uint32_t drop_key, uint32_t* drop_bits, void* stream);
 /* dbias_qkv (fp32 [3*H*hd], optional): += column sums of dqkv (bias gradient of the fused QKV projection), taken from the
  * fp32 accumulators.  dbias_ws: fp32 [B, 3*H*hd] scratch, required with dbias_qkv when N <= 224 (every head writes its sums to
  * its batch element's row with plain stores and a small second launch folds the rows into dbias_qkv); longer sequences (two-pass
  * kernels) add with one atomic per workgroup and column and ignore it. */
 int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N,
-                      int H, int hd, float drop_rate, uint32_t drop_key, float* dbias_qkv, float* dbias_ws, void* stream);
+                      int H, int hd, float drop_rate, uint32_t drop_key, float* dbias_qkv, float* dbias_ws,
+                      const uint32_t* drop_bits, void* stream);
 
 /* ---------------------------------------------------------------- input side */
 #define CHB_DT_U8 0

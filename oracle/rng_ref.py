@@ -51,3 +51,15 @@ def keep_mask(n_elements, key, rate):
     r = hash32(((e >> np.uint64(1)) ^ np.uint64(key)) & np.uint64(0xFFFFFFFF)).astype(np.uint64)
     u16 = (r >> (np.uint64(16) * (e & np.uint64(1)))) & np.uint64(0xFFFF)
     return u16 >= np.uint64(threshold(rate))
+
+
+def attn_keep_mask(shape, key, rate):
+    """Keep mask of the dropout on the attention probabilities, bool of ``shape`` = [B, H, N, N].  The element index of
+    (b, h, q, k) is ((b*H + h)*N + q)*Np4 + k with the ROW STRIDE Np4 = N rounded up to a multiple of 4 (every query row starts
+    on a hash-pair boundary, so the four consecutive keys a lane of the kernels holds are the halves of exactly two hashes);
+    otherwise as `keep_mask`."""
+    b, h, n, n2 = (int(v) for v in shape)
+    assert n == n2
+    np4 = (n + 3) & ~3
+    full = keep_mask(b * h * n * np4, key, rate).reshape(b, h, n, np4)
+    return np.ascontiguousarray(full[..., :n])

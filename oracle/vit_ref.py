@@ -93,7 +93,9 @@ def multi_head_attention(x, p, prefix, num_heads, rate, key, bf16):
     scores = torch.matmul(query, keyt.transpose(-1, -2)) / math.sqrt(head_dim)
     if not bf16:
         weights = torch.softmax(scores, dim=-1)
-        weights = _drop(weights, rate, key)
+        if rate != 0.0 and key is not None:     # keras Attention dropout on the probabilities; mask index: rng_ref.attn_keep_mask
+            keep = rng_ref.attn_keep_mask(tuple(weights.shape), key, rate)
+            weights = weights * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * torch.from_numpy(keep).to(weights.dtype)
         attn = torch.matmul(weights, value)
     else:
         # same mathematics with the build's rounding points: the un-normalised exponentials (masked by the
@@ -103,7 +105,7 @@ def multi_head_attention(x, p, prefix, num_heads, rate, key, bf16):
         denom = pt.sum(dim=-1, keepdim=True)
         scale = 1.0
         if rate != 0.0 and key is not None:
-            keep = rng_ref.keep_mask(pt.numel(), key, rate).reshape(tuple(pt.shape))
+            keep = rng_ref.attn_keep_mask(tuple(pt.shape), key, rate)
             pt = pt * torch.from_numpy(keep).to(pt.dtype)
             scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
         attn = torch.matmul(_bf(pt, True), value) * (scale / denom)

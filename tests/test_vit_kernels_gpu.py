@@ -479,7 +479,7 @@ def _attn_ref(qkv, bsz, n, h, rate, key):
     p = torch.softmax(s, dim=-1)
     lse = torch.logsumexp(s, dim=-1)
     if rate:
-        keep = torch.from_numpy(rng_ref.keep_mask(p.numel(), key, rate).reshape(p.shape))
+        keep = torch.from_numpy(rng_ref.attn_keep_mask(tuple(p.shape), key, rate))
         p = p * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * keep
     o = (p @ v).permute(0, 2, 1, 3).reshape(bsz * n, d)
     return o, lse
@@ -487,17 +487,26 @@ def _attn_ref(qkv, bsz, n, h, rate, key):
 
 @pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.0), (2, 197, 3, 0.1), (3, 17, 2, 0.1), (1, 64, 1, 0.0), (2, 33, 4, 0.5),
                                           (1, 128, 2, 0.1), (1, 577, 2, 0.1), (1, 1, 1, 0.0), (2, 224, 1, 0.1), (2, 225, 2, 0.1),
-                                          (1, 577, 3, 0.0), (1, 608, 1, 0.1), (2, 257, 1, 0.25), (1, 785, 1, 0.1)])
-def test_attention_fwd_bwd(bsz, n, h, rate):
+                                          (1, 577, 3, 0.0), (1, 608, 1, 0.1), (2, 257, 1, 0.25), (1, 785, 1, 0.1),
+                                          # more heads than CUs: the persistent backward walks two heads per workgroup (2 / 4 / 7 blocks per head)
+                                          (40, 50, 8, 0.1), (30, 100, 9, 0.1), (23, 197, 12, 0.1)])
+@pytest.mark.parametrize("variant", ["dbias", "lean", "lean_bits"])
+def test_attention_fwd_bwd(bsz, n, h, rate, variant):
+    """variant: "dbias" = backward with the fused QKV bias gradient (the 16-wave kernel with the bias epilogue, or the two-pass
+    kernels); "lean" = the lean one-pass kernel regenerating the dropout mask by hashing; "lean_bits" = the same kernel testing
+    the keep bits the forward wrote."""
     from chambers_amd import kernels as K
     d = h * 64
     key = 0x1234567
+    bits = K.attention_drop_bits(bsz, n, h) if variant == "lean_bits" else None
+    if bits is not None:
+        bits.fill_(-1)
     qkv = bf(torch.randn(bsz * n, 3 * d, generator=g(40)))
     qkv_ref = qkv.double().requires_grad_(True)
     o_ref, lse_ref = _attn_ref(qkv_ref, bsz, n, h, rate, key)
     o = torch.empty(bsz * n, d, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(bsz * h * n, dtype=torch.float32, device="cuda")
-    K.attention_fwd(qkv.cuda(), o, lse, bsz, n, h, 64, rate, key)
+    K.attention_fwd(qkv.cuda(), o, lse, bsz, n, h, 64, rate, key, drop_bits=bits)
     scale = float(o_ref.detach().abs().max())
     err = (o.float().cpu().double() - o_ref.detach()).abs().max().item()
     assert err <= scale * 2 ** -7, "attention fwd max err %g vs scale %g" % (err, scale)
@@ -506,12 +515,22 @@ def test_attention_fwd_bwd(bsz, n, h, rate):
     do = bf(torch.randn(bsz * n, d, generator=g(41)))   # n > 224 runs the two-pass backward (dK/dV pass + dQ pass)
     o_ref.backward(do.double())
     dqkv = torch.zeros(bsz * n, 3 * d, dtype=torch.bfloat16, device="cuda")
-    dbias = torch.zeros(3 * d, device="cuda")
-    K.attention_bwd(qkv.cuda(), o, do.cuda(), lse, dqkv, bsz, n, h, 64, rate, key, dbias=dbias)
     gref = qkv_ref.grad
-    rb = rel_l2(dbias.cpu()[d:], gref.sum(0)[d:])             # fused bias gradient (column sums); the key part is ~0 by symmetry
-    assert rel_l2(dbias.cpu()[:d], gref.sum(0)[:d]) < 1e-2 and rel_l2(dbias.cpu()[2 * d:], gref.sum(0)[2 * d:]) < 1e-2, rb
-    assert float(dbias[d:2 * d].abs().max()) < 2e-2 * float(dbias.abs().max() + 1e-6)
+    if variant == "dbias":
+        dbias = torch.zeros(3 * d, device="cuda")
+        K.attention_bwd(qkv.cuda(), o, do.cuda(), lse, dqkv, bsz, n, h, 64, rate, key, dbias=dbias)
+        rb = rel_l2(dbias.cpu()[d:], gref.sum(0)[d:])             # fused bias gradient (column sums); the key part is ~0 by symmetry
+        assert rel_l2(dbias.cpu()[:d], gref.sum(0)[:d]) < 1e-2 and rel_l2(dbias.cpu()[2 * d:], gref.sum(0)[2 * d:]) < 1e-2, rb
+        assert float(dbias[d:2 * d].abs().max()) < 2e-2 * float(dbias.abs().max() + 1e-6)
+    else:
+        K.attention_bwd(qkv.cuda(), o, do.cuda(), lse, dqkv, bsz, n, h, 64, rate, key, drop_bits=bits)
+        if bits is not None and rate and n <= 224:
+            # the saved bits ARE the mask definition: bit 16(r&1) + 8(r>>1) + (t & 7) of word ((bh*N + q)*4 + g)*2 + (t >> 3) <-> key 16t + 4g + r
+            keep = rng_ref.attn_keep_mask((bsz, h, n, n), key, rate)
+            w = bits.cpu().numpy().view(np.uint32).reshape(bsz, h, n, 4, 2)
+            kk = np.arange(n)
+            got = (w[..., (kk >> 2) & 3, kk >> 7] >> (16 * (kk & 1) + 8 * ((kk >> 1) & 1) + ((kk >> 4) & 7)).astype(np.uint32)) & 1
+            np.testing.assert_array_equal(got.astype(bool), keep)
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         r = rel_l2(dqkv[:, sl].float().cpu(), gref[:, sl])
         assert r < 1e-2, "%s rel-l2 %g" % (name, r)

@@ -1,4 +1,5 @@
-"""Attention kernel timings: python tools/attn_bench.py [B N H].  Prints forward, one-pass and two-pass backward."""
+"""Attention kernel timings: python tools/attn_bench.py [B N H].  Forward: whole-head (default), resident, streaming; backward:
+lean one-pass with / without the forward's keep bits (default), 16-wave and 8-wave resident, two-pass, fused bias gradient."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +12,7 @@ o = torch.empty(B * N, D, dtype=torch.bfloat16, device="cuda")
 do = torch.randn(B * N, D, device="cuda").to(torch.bfloat16)
 dqkv = torch.empty(B * N, 3 * D, dtype=torch.bfloat16, device="cuda")
 lse = torch.empty(B * H * N, device="cuda")
+bits = K.attention_drop_bits(B, N, H)
 
 
 def t(fn, it=10):
@@ -23,24 +25,29 @@ def t(fn, it=10):
 
 
 fl = 4.0 * B * H * N * N * 64
+hbm_f = (B * N * 4 * D * 2) / 1e9                     # qkv read + o written, GB
+hbm_b = (B * N * (3 * D + 2 * D + 3 * D) * 2) / 1e9   # qkv, o, do read + dqkv written
 for rate in (0.0, 0.1):
-    line = "B %d N %d H %d rate %.1f " % (B, N, H, rate)
-    for algo in ("1", "2"):
-        if algo == "1" and N > 224:
+    line = "B %d N %d H %d rate %.1f\n" % (B, N, H, rate)
+    for algo, label in ((0, "head"), (1, "resident"), (2, "stream")):
+        if (algo == 1 and N > 224):
             continue
-        _lib.set_option("ATTN_FWD_ALGO", int(algo))
-        f = t(lambda: K.attention_fwd(qkv, o, lse, B, N, H, 64, rate, 7))
-        line += "   fwd[%s] %.3f ms (%.0f TF/s)" % ("resident" if algo == "1" else "stream", f, fl / f / 1e9)
-    for algo, label in (("0", "default"), ("1", "resident 8 waves"), ("2", "two-pass")):
-        if algo == "1" and N > 224:
+        _lib.set_option("ATTN_FWD_ALGO", algo)
+        f = t(lambda: K.attention_fwd(qkv, o, lse, B, N, H, 64, rate, 7, drop_bits=bits if rate else None))
+        line += "   fwd[%s] %.3f ms (%.0f TF/s, %.2f TB/s algorithmic)\n" % (label, f, fl / f / 1e9, hbm_f / f)
+    _lib.set_option("ATTN_FWD_ALGO", 0)
+    K.attention_fwd(qkv, o, lse, B, N, H, 64, rate, 7, drop_bits=bits if rate else None)
+    for algo, label, kw in ((0, "lean + keep bits", dict(drop_bits=bits if rate else None)), (0, "lean, hashing", {}),
+                            (3, "resident 16 waves", {}), (1, "resident 8 waves", {}), (2, "two-pass", {})):
+        if algo in (1, 3) and N > 224:
             continue
-        _lib.set_option("ATTN_BWD_ALGO", int(algo))
-        b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7))
-        line += "   bwd[%s] %.3f ms (%.0f TF/s)" % (label, b, 2.5 * fl / b / 1e9)
+        _lib.set_option("ATTN_BWD_ALGO", algo)
+        b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7, **kw))
+        line += "   bwd[%s] %.3f ms (%.0f TF/s, %.2f TB/s algorithmic)\n" % (label, b, 2.5 * fl / b / 1e9, hbm_b / b)
     _lib.set_option("ATTN_BWD_ALGO", 0)
     dbias = torch.zeros(3 * D, device="cuda")
     ws = torch.empty(B * 3 * D, device="cuda")
     b = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7, dbias=dbias, dbias_ws=ws))
     c = t(lambda: K.colsum(dqkv, dbias, m=B * N))
-    line += "   bwd[default + fused qkv bias gradient] %.3f ms   (stand-alone column sums of dqkv: %.3f ms)" % (b, c)
+    line += "   bwd[16 waves + fused qkv bias gradient] %.3f ms   (stand-alone column sums of dqkv: %.3f ms)" % (b, c)
     print(line, flush=True)
