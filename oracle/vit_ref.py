@@ -55,6 +55,89 @@ def _bf(x, on):
     return x.to(torch.bfloat16).to(torch.float32) if on else x
 
 
+# ---- bf16 emulation of the BACKWARD rounding points (bf16=True only) ------------------------- #
+# The build stores every GEMM / attention operand of the backward pass in bf16 as well: dz (dropout-backward of the residual
+# gradient), d(pre-activation) = (dz . W2^T) * gelu'(a) with gelu' itself SAVED in bf16, dO, dqkv, d(LayerNorm output).  The
+# plain `_bf` cast already rounds the gradient of a tensor it rounded in the forward (autograd of .to(bfloat16)); the functions
+# below add the points a cast cannot express, so that "engine vs emulating oracle" isolates real defects from rounding.
+class _RoundGrad(torch.autograd.Function):
+    """identity forward; the gradient is rounded to bf16 (a gradient tensor the build stores in bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class _BfForwardOnly(torch.autograd.Function):
+    """bf16 rounding in the forward, identity in the backward (the consumer's backward does its own rounding)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GeluSavedDerivative(torch.autograd.Function):
+    """gelu with the build's backward: d(pre-activation) = bf16(incoming fp32 accumulator * bf16(gelu'(a)))."""
+
+    @staticmethod
+    def forward(ctx, a):
+        cdf = 0.5 * (1.0 + torch.erf(a / 1.4142135623730951))
+        d = cdf + a * torch.exp(-0.5 * a * a) * 0.3989422804014327
+        ctx.save_for_backward(d.to(torch.bfloat16).to(torch.float32))
+        return a * cdf
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return (g * d).to(torch.bfloat16).to(torch.float32)
+
+
+class _AttentionBf16(torch.autograd.Function):
+    """Scaled dot-product attention with dropout on the probabilities, rounding points of the HIP kernels in BOTH directions:
+    forward - un-normalised exponentials (times the keep mask) rounded to bf16 for P.V, 1/sum and 1/(1-rate) on the fp32 result,
+    output stored bf16; backward (csrc/attention.hip, lean kernel) - probabilities recomputed from the saved log-sum-exp in fp32,
+    P*keep/(1-rate) and dS = P*(dP*keep/(1-rate) - delta) rounded to bf16 as MFMA operands, delta = rowsum(dO * O) with the
+    stored bf16 O, 1/sqrt(hd) applied to dQ / dK at the store, dQ / dK / dV stored bf16."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, keep, inv_keep, scale):
+        bf = lambda t: t.to(torch.bfloat16).to(torch.float32)   # noqa: E731
+        s = torch.matmul(q, k.transpose(-1, -2)) * scale
+        mx = s.max(dim=-1, keepdim=True).values
+        pt = torch.exp(s - mx)
+        denom = pt.sum(dim=-1, keepdim=True)
+        lse = mx + torch.log(denom)
+        ptd = pt * keep if keep is not None else pt
+        o = bf(torch.matmul(bf(ptd), v) * (inv_keep / denom))
+        ctx.save_for_backward(q, k, v, o, lse, keep if keep is not None else torch.ones(()))
+        ctx.has_keep, ctx.inv_keep, ctx.scale = keep is not None, inv_keep, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        bf = lambda t: t.to(torch.bfloat16).to(torch.float32)   # noqa: E731
+        q, k, v, o, lse, keep = ctx.saved_tensors
+        do = bf(do)
+        p = torch.exp(torch.matmul(q, k.transpose(-1, -2)) * ctx.scale - lse)
+        keepc = (keep * ctx.inv_keep) if ctx.has_keep else 1.0
+        delta = (do * o).sum(dim=-1, keepdim=True)
+        dp = torch.matmul(do, v.transpose(-1, -2))
+        pd = bf(p * keepc)
+        ds = bf(p * (dp * keepc - delta))
+        dv = bf(torch.matmul(pd.transpose(-1, -2), do))
+        dk = bf(torch.matmul(ds.transpose(-1, -2), q) * ctx.scale)
+        dq = bf(torch.matmul(ds, k) * ctx.scale)
+        return dq, dk, dv, None, None, None
+
+
 def _drop(x, rate, key):
     """tf.nn.dropout: x * 1/(1-rate) * keep (keras Dropout, training)."""
     if rate == 0.0 or key is None:
@@ -77,8 +160,9 @@ def layer_norm(x, gamma, beta, eps):
     return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
 
 
-def multi_head_attention(x, p, prefix, num_heads, rate, key, bf16):
-    """layers/attention.py:99-127 with q = v = k = x (layers/transformer.py:66-68)."""
+def multi_head_attention(x, p, prefix, num_heads, rate, key, bf16, taps=None):
+    """layers/attention.py:99-127 with q = v = k = x (layers/transformer.py:66-68).  taps (dict, optional): receives the
+    projected "q", "k", "v" [B,H,N,hd] and the attention output "o" (gradients retained) under prefix + name."""
     wq, bq = p[prefix + "w_query"], p[prefix + "b_query"]
     wv, bv = p[prefix + "w_value"], p[prefix + "b_value"]
     wk, bk = p[prefix + "w_key"], p[prefix + "b_key"]
@@ -88,43 +172,66 @@ def multi_head_attention(x, p, prefix, num_heads, rate, key, bf16):
     query = torch.einsum("btd,dnh->bnth", xb, _bf(wq, bf16)) + bq
     value = torch.einsum("btd,dnh->bnth", xb, _bf(wv, bf16)) + bv
     keyt = torch.einsum("btd,dnh->bnth", xb, _bf(wk, bf16)) + bk
-    query, value, keyt = _bf(query, bf16), _bf(value, bf16), _bf(keyt, bf16)
+    if bf16:
+        # operands stored bf16 by the QKV GEMM; their gradients (dqkv) are rounded by the attention backward itself
+        query, value, keyt = _BfForwardOnly.apply(query), _BfForwardOnly.apply(value), _BfForwardOnly.apply(keyt)
+    if taps is not None:
+        for nm, t in (("q", query), ("k", keyt), ("v", value)):
+            if t.requires_grad:
+                t.retain_grad()
+            taps[prefix + nm] = t
+    if bf16:
+        keep, inv_keep = None, 1.0
+        if rate != 0.0 and key is not None:
+            keep = torch.from_numpy(rng_ref.attn_keep_mask((x.shape[0], num_heads, x.shape[1], x.shape[1]), key, rate)).to(torch.float32)
+            inv_keep = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
+        attn = _AttentionBf16.apply(query, keyt, value, keep, inv_keep, 1.0 / math.sqrt(head_dim))
+        if taps is not None:
+            if attn.requires_grad:
+                attn.retain_grad()
+            taps[prefix + "o"] = attn
+        return torch.einsum("bnth,ndh->btd", attn, _bf(wp, bf16)) + bp
     # ScaledAttention._calculate_scores (layers/attention.py:13-23): matmul, THEN divide
     scores = torch.matmul(query, keyt.transpose(-1, -2)) / math.sqrt(head_dim)
-    if not bf16:
-        weights = torch.softmax(scores, dim=-1)
-        if rate != 0.0 and key is not None:     # keras Attention dropout on the probabilities; mask index: rng_ref.attn_keep_mask
-            keep = rng_ref.attn_keep_mask(tuple(weights.shape), key, rate)
-            weights = weights * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * torch.from_numpy(keep).to(weights.dtype)
-        attn = torch.matmul(weights, value)
-    else:
-        # same mathematics with the build's rounding points: the un-normalised exponentials (masked by the
-        # dropout keep-mask) are rounded to bf16 for the P.V product; 1/sum and 1/(1-rate) scale the fp32 result
-        mx = scores.max(dim=-1, keepdim=True).values
-        pt = torch.exp(scores - mx)
-        denom = pt.sum(dim=-1, keepdim=True)
-        scale = 1.0
-        if rate != 0.0 and key is not None:
-            keep = rng_ref.attn_keep_mask(tuple(pt.shape), key, rate)
-            pt = pt * torch.from_numpy(keep).to(pt.dtype)
-            scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
-        attn = torch.matmul(_bf(pt, True), value) * (scale / denom)
-    attn = _bf(attn, bf16)
+    weights = torch.softmax(scores, dim=-1)
+    if rate != 0.0 and key is not None:     # keras Attention dropout on the probabilities; mask index: rng_ref.attn_keep_mask
+        keep = rng_ref.attn_keep_mask(tuple(weights.shape), key, rate)
+        weights = weights * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * torch.from_numpy(keep).to(weights.dtype)
+    attn = torch.matmul(weights, value)
+    if taps is not None:
+        if attn.requires_grad:
+            attn.retain_grad()
+        taps[prefix + "o"] = attn
     return torch.einsum("bnth,ndh->btd", attn, _bf(wp, bf16)) + bp
 
 
-def encoder_layer(x, p, prefix, cfg, keys, layer, bf16):
+def encoder_layer(x, p, prefix, cfg, keys, layer, bf16, taps=None):
     """EncoderLayer.call pre-norm branch, layers/transformer.py:56-58,65-77."""
     rate = cfg["dropout_rate"]
     eps = cfg.get("norm_epsilon", 1e-6)
     h = layer_norm(x, p[prefix + "norm1/gamma"], p[prefix + "norm1/beta"], eps)
+    if taps is not None:
+        taps[prefix + "h1"] = h
     a = multi_head_attention(h, p, prefix + "multi_head_attention/", cfg["n_heads"], rate,
-                             keys.get(site_attn(layer)), bf16)
+                             keys.get(site_attn(layer)), bf16, taps)
+    if bf16:
+        a = _RoundGrad.apply(a)          # dz = bf16(dropout-backward of the residual gradient): operand of the projection's backward GEMMs
     x = x + _drop(a, rate, keys.get(site_proj(layer)))
     h = layer_norm(x, p[prefix + "norm2/gamma"], p[prefix + "norm2/beta"], eps)
-    u = gelu(torch.matmul(_bf(h, bf16), _bf(p[prefix + "dense1/kernel"], bf16)) + p[prefix + "dense1/bias"])
-    y = torch.matmul(_bf(u, bf16), _bf(p[prefix + "dense2/kernel"], bf16)) + p[prefix + "dense2/bias"]
-    return x + _drop(y, rate, keys.get(site_mlp(layer)))
+    if taps is not None:
+        taps[prefix + "xmid"], taps[prefix + "h2"] = x, h
+    a1 = torch.matmul(_bf(h, bf16), _bf(p[prefix + "dense1/kernel"], bf16)) + p[prefix + "dense1/bias"]
+    if bf16:
+        u = _BfForwardOnly.apply(_GeluSavedDerivative.apply(a1))    # u stored bf16; d(a1) = bf16(fp32 accumulator * saved bf16 gelu')
+    else:
+        u = gelu(a1)
+    y = torch.matmul(u, _bf(p[prefix + "dense2/kernel"], bf16)) + p[prefix + "dense2/bias"]
+    if bf16:
+        y = _RoundGrad.apply(y)          # dz of the MLP branch
+    out = x + _drop(y, rate, keys.get(site_mlp(layer)))
+    if taps is not None:
+        taps[prefix + "u"], taps[prefix + "xout"] = u, out
+    return out
 
 
 def patch_embed(images, kernel, bias, patch, bf16):
@@ -138,7 +245,7 @@ def patch_embed(images, kernel, bias, patch, bf16):
     return torch.matmul(_bf(x, bf16), _bf(k2, bf16)) + bias
 
 
-def vit_forward(p, images, cfg, keys=None, bf16=False, return_tokens=False):
+def vit_forward(p, images, cfg, keys=None, bf16=False, return_tokens=False, taps=None):
     """VisionTransformer graph, vision_transformer.py:235-283.
     ``images``: float32 NHWC, already normalised.  ``keys``: {site: key} for
     training-mode dropout, None/{} for inference.  Returns logits (or the
@@ -155,8 +262,10 @@ def vit_forward(p, images, cfg, keys=None, bf16=False, return_tokens=False):
     x = torch.cat([cls, x], dim=1)                       # ConcatEmbedding side="left": [cls, (dist,) patches]
     x = x + p["pos_embedding/embeddings"]                # LearnedEmbedding1D
     x = _drop(x, rate, keys.get(SITE_EMBED))
+    if taps is not None:
+        taps["x0"] = x
     for i in range(cfg["n_encoder_layers"]):
-        x = encoder_layer(x, p, "encoder/layer_%d/" % i, cfg, keys, i, bf16)
+        x = encoder_layer(x, p, "encoder/layer_%d/" % i, cfg, keys, i, bf16, taps)
     x = layer_norm(x, p["encoder/norm/gamma"], p["encoder/norm/beta"],
                    cfg.get("norm_epsilon", 1e-6))
     if return_tokens:
