@@ -239,6 +239,8 @@ def main():
     ap.add_argument("--no-augment", action="store_true")
     ap.add_argument("--augment", default="randaugment", choices=("randaugment", "autoaugment"),
                     help="on-GPU augmentation stage: RandAugment(2, 9) (configs 3/4) or AutoAugment policy v0 (config 5)")
+    ap.add_argument("--elementwise", action="store_true", help="per-image augmentation decisions (the schemes' elementwise=True mode)")
+    ap.add_argument("--unfused-augment", action="store_true", help="batch-shared chain as one launch per op + a separate patchify pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N ranks on one GPU")
     args = ap.parse_args()
 
@@ -276,19 +278,39 @@ def main():
     images = torch.as_tensor(g.integers(0, 256, size=(args.batch, args.image_size, args.image_size, 3), dtype=np.uint8), device="cuda")
     labels = torch.as_tensor(g.integers(0, 1000, size=(args.batch,)), device="cuda")
     gd = np.random.Generator(np.random.PCG64(42 + rank))            # augmentation decisions, host side
-    randaug = aug.RandAugment(2, 9)
-    autoaug = aug.AutoAugment()
+    randaug = aug.RandAugment(2, 9, elementwise=args.elementwise)
+    autoaug = aug.AutoAugment(elementwise=args.elementwise)
+    if args.unfused_augment:
+        randaug._transform.fused = False
+        autoaug.fused = False
+
+    hw = (args.image_size, args.image_size)
+
+    def autoaugment_decision():
+        pol = int(gd.integers(0, 25))
+        sub = aug.augmentation_schemes._AUTO_AUGMENT_POLICY_V0[pol]
+        return {"policy": pol, "apply": tuple(bool(gd.uniform() < p) for (_t, p, _m) in sub), "negate": (bool(gd.uniform() < 0.5), bool(gd.uniform() < 0.5))}
 
     def step():
-        x = images
+        x, plan = images, None
         if not args.no_augment:
-            if args.augment == "autoaugment":
-                pol = int(gd.integers(0, 25))
-                x = autoaug(images, training=True, decision={"policy": pol, "apply": (bool(gd.uniform() < 0.5), bool(gd.uniform() < 0.5)),
-                                                             "negate": (bool(gd.uniform() < 0.5), bool(gd.uniform() < 0.5))})
+            if args.elementwise:
+                # per-image decisions (elementwise=True, the reference's tf.map_fn mode): one dispatch launch per slot, then the
+                # normalise + patchify pass of the engine
+                if args.augment == "autoaugment":
+                    x = autoaug(images, training=True, decision=[autoaugment_decision() for _ in range(args.batch)])
+                else:
+                    x = randaug(images, training=True, decisions=[[{"op": int(gd.integers(0, 16)), "negate": bool(gd.uniform() < 0.5),
+                                                                    "centers": (int(gd.integers(0, hw[0])), int(gd.integers(0, hw[1])))}
+                                                                   for _ in range(2)] for _ in range(args.batch)])
+            elif args.unfused_augment:
+                x = (autoaug(images, training=True, decision=autoaugment_decision()) if args.augment == "autoaugment" else
+                     randaug(images, training=True, decisions=draw_randaugment_decisions(gd, 2, args.batch, *hw)))
             else:
-                x = randaug(images, training=True, decisions=draw_randaugment_decisions(gd, 2, args.batch, args.image_size, args.image_size))
-        return eng.train_step(x, labels, learning_rate=1e-3, weight_decay=0.05)
+                # batch-shared decisions (the schemes' default): the chain is evaluated inside the engine's normalise + patchify pass
+                plan = (autoaug.plan(images.shape, autoaugment_decision()) if args.augment == "autoaugment" else
+                        randaug.plan(images.shape, draw_randaugment_decisions(gd, 2, args.batch, *hw)))
+        return eng.train_step(x, labels, augment=plan, learning_rate=1e-3, weight_decay=0.05)
 
     for _ in range(args.warmup):
         step()
@@ -296,6 +318,9 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    red = eng.reducer
+    red.measure = True
+    red.n_collectives = red.bytes_reduced = 0
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -328,7 +353,8 @@ def main():
             "config": {"workload": "%s train step, batch %d/GPU, %dx%d, on-GPU %s%s, dropout 0.1, AdamW, dp%d"
                        % (args.model, args.batch, args.image_size, args.image_size,
                           "AutoAugment(policy v0)" if args.augment == "autoaugment" else "RandAugment(n=2,m=9)",
-                          " OFF" if args.no_augment else "", world),
+                          " OFF" if args.no_augment else (" elementwise" if args.elementwise else (" op-by-op" if args.unfused_augment else " fused")),
+                          world),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
             # dominant kernel FAMILY (all template instantiations together): achieved = sum of 2*M*N*K over its launches / sum of
             # their durations (HIP events on the launch stream, inside the timed region)
@@ -343,6 +369,13 @@ def main():
             "kernels": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 1), "launches": v["launches"],
                             "total_ms": round(v["total_ms"], 2)} for k, v in ks.items()},
             "final_loss": final_loss,
+            # the data-parallel exchange, as this run did it: collectives per step, bytes all-reduced per step per rank, and the
+            # time per step the compute stream waited for them (HIP events around the reducer's waits on rank 0)
+            "dp": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
+                   "world_size": dist.get_world_size() if dist is not None else 1,
+                   "allreduce_bytes_per_step": red.bytes_reduced / args.steps, "collectives_per_step": red.n_collectives / args.steps,
+                   "exposed_comm_ms_per_step": red.exposed_ms() / args.steps,
+                   "gradient_bytes": int(eng.G.numel() * eng.G.element_size())},
         }
         # HBM-side bytes per launch of the dominant kernel: PMC counters need their own rocprofv3 passes (tools/pmc_bench.sh runs
         # them over this same command); the committed summary is quoted here when it was taken on this workload

@@ -153,7 +153,22 @@ class AutoAugment(Layer):
         negate = tuple(bool(g.uniform() < 0.5) for _ in sub)
         return {"policy": policy, "apply": apply, "negate": negate}
 
+    def plan(self, input_shape, decision=None):
+        """The batch-shared call resolved to op records (kernels.AugPlan): the drawn sub-policy's two RandomChance steps."""
+        from .. import kernels as K
+        decision = decision if decision is not None else self.draw_decision()
+        b, h, w = int(input_shape[0]), int(input_shape[1]), int(input_shape[2])
+        seq = self.transforms[int(decision["policy"])]
+        pairs = [image_augmentations.batch_item(chance, b, h, w, apply=bool(decision["apply"][j]), negate=bool(decision["negate"][j]))
+                 for j, chance in enumerate(seq.layers)]
+        return K.AugPlan([p[0] for p in pairs], [p[1] for p in pairs])
+
+    fused = True      # one launch for the pair (chb_aug_fused); False = one launch per applied op
+
     def _apply(self, inputs, decision):
+        if self.fused and inputs.dim() == 4 and inputs.shape[-1] == 3 and inputs.shape[0] > 0:
+            from .. import kernels as K
+            return K.aug_fused(inputs, self.plan(inputs.shape, decision))
         seq = self.transforms[int(decision["policy"])]
         x = inputs
         for j, chance in enumerate(seq.layers):
@@ -230,6 +245,15 @@ class RandAugment(Layer):
             return self._transform(inputs, choices=[p[0] for p in pairs], slot_kwargs=[p[1] for p in pairs])
         choices, kws = split(decisions)
         return self._transform(inputs, choices=choices, slot_kwargs=kws)
+
+    def plan(self, input_shape, decisions=None):
+        """The batch-shared call resolved to op records (kernels.AugPlan) - what ViTEngine.forward(..., augment=plan) fuses
+        into its normalise + patchify pass."""
+        if self.elementwise:
+            raise ValueError("plan() describes the batch-shared mode; elementwise=True runs the per-image dispatch kernel")
+        if decisions is None:
+            return self._transform.plan(input_shape)
+        return self._transform.plan(input_shape, [int(d["op"]) for d in decisions], [{k: v for k, v in d.items() if k != "op"} for d in decisions])
 
     def compute_output_shape(self, input_shape):
         return self._transform.compute_output_shape(input_shape)

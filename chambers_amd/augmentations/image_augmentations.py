@@ -408,6 +408,29 @@ class CutOut(Layer):
         return _base_cfg(self, {"mask_size": self.mask_size, "constant_values": self.constant_values})
 
 
+def batch_item(transform, batch, height, width, **kwargs):
+    """(op record, per-image cutout centres or None) of `transform` applied to a whole [batch, height, width, 3] tensor: the
+    record of dispatch_item (which describes a batch of ONE image) with the two things that differ for a batch put right -
+    Contrast's constant counts the pixels of the whole tensor (:253-257), CutOut draws one centre per image (:497-503)."""
+    if isinstance(transform, RandomChance):
+        apply = kwargs.pop("apply", None)
+        if apply is None:
+            apply = bool(rng.host_generator().uniform() < transform.probability)
+        if not apply:
+            return K.aug_item(_lib.AUG_IDENTITY), None
+        return batch_item(transform.transform, batch, height, width, **kwargs)
+    if isinstance(transform, Contrast):
+        return K.aug_item(_lib.AUG_CONTRAST, i=(transform.degenerate_constant(batch * height * width),), f=(transform.factor,)), None
+    if isinstance(transform, CutOut):
+        centers = kwargs.get("centers")
+        if centers is None:
+            g = rng.host_generator()
+            centers = np.stack([g.integers(0, height, size=batch), g.integers(0, width, size=batch)], axis=1)
+        centers = np.ascontiguousarray(centers, dtype=np.int32).reshape(batch, 2)
+        return transform.dispatch_item(height, width, centers=(0, 0)), centers
+    return transform.dispatch_item(height, width, **kwargs), None
+
+
 # ---------------------------------------------------------------- combinators
 @register_keras_serializable(package="Chambers")
 class RandomChance(Layer):
@@ -496,6 +519,8 @@ class RandomChoice(Layer):
         return x
 
     def _random_transforms(self, inputs, choices=None, slot_kwargs=None):
+        if self._can_fuse(inputs):
+            return K.aug_fused(inputs, self.plan(inputs.shape, choices, slot_kwargs))
         for i in range(self.n_transforms):
             if choices is None:
                 idx = int(rng.host_generator().integers(0, len(self.transforms)))
@@ -504,6 +529,25 @@ class RandomChoice(Layer):
             kw = {} if slot_kwargs is None else dict(slot_kwargs[i])
             inputs = self.transforms[idx](inputs, **kw)
         return inputs
+
+    fused = True      # batch-shared chains of describable ops run as ONE launch (chb_aug_fused); False = one launch per op
+
+    def _can_fuse(self, inputs):
+        return (self.fused and 1 <= self.n_transforms <= K.FUSED_MAX_OPS and inputs.dim() == 4 and inputs.shape[-1] == 3
+                and inputs.dtype == torch.uint8 and inputs.shape[0] > 0 and all(hasattr(t, "dispatch_item") for t in self.transforms))
+
+    def plan(self, input_shape, choices=None, slot_kwargs=None):
+        """Resolve one batch-shared call to op records (K.AugPlan), drawing what was not given in the order the op-by-op route
+        draws it: per slot the transform index, then whatever the chosen transform draws (sign, chance, cutout centres)."""
+        b, h, w = int(input_shape[0]), int(input_shape[1]), int(input_shape[2])
+        items, centers = [], []
+        for i in range(self.n_transforms):
+            idx = int(rng.host_generator().integers(0, len(self.transforms))) if choices is None else int(choices[i])
+            kw = {} if slot_kwargs is None else dict(slot_kwargs[i])
+            item, cen = batch_item(self.transforms[idx], b, h, w, **kw)
+            items.append(item)
+            centers.append(cen)
+        return K.AugPlan(items, centers)
 
     def compute_output_shape(self, input_shape):
         shapes = [t.compute_output_shape(input_shape) for t in self.transforms]

@@ -11,6 +11,7 @@
 // kernel); upstream TF / tensorflow-addons behaviour as restated in oracle/augment_ref.py.
 #include "common.hpp"
 #include "../../include/chambers_hip.h"
+#include <string.h>
 
 namespace {
 
@@ -1149,6 +1150,229 @@ __global__ void __launch_bounds__(256) aug_dispatch_kernel(const uint8_t* __rest
     }
 }
 
+// ---- fused scheme stage: RandAugment / AutoAugment (batch-shared decisions) -> [normalise -> bf16 patch rows] -------------------
+// augmentation_schemes.py:204-213 (RandAugment.call) / :151-160 -> image_augmentations.py:659-665 -> vision_transformer.py:235-248.
+// The unfused path runs every selected op as its own HBM round trip and then the normalise + patchify pass (n + 1 passes).  Here the
+// output pixel is EVALUATED: level L of the chain is a function of level L-1 at the same pixel (pointwise ops, table ops), at
+// another pixel (nearest-neighbour warp, CutOut keeps or replaces) or at the 3x3 neighbourhood (Sharpness), down to a load of the
+// untouched input - the arithmetic of every level is the stand-alone kernel's, so the result is bit-identical to the op chain.  One
+// read of the uint8 batch (re-reads of neighbours come from L1 / L2), one write (uint8 image, or bf16 patch rows with the "tf"
+// normalisation applied); AutoContrast / Equalize at level L cost one extra pass: the histogram of level L-1 (evaluated the same
+// way) and the table kernel, before the final launch.
+struct FusedOp {
+    int32_t op;          // CHB_AUG_*
+    int32_t i0, i1, i2, i3;
+    float f[6];
+    int32_t pad;
+};
+struct FusedParams {
+    int32_t n;
+    FusedOp ops[CHB_FUSED_MAX_OPS];
+    const int32_t* lut[CHB_FUSED_MAX_OPS];        // level's [B][3][256] table (AutoContrast / Equalize), else NULL
+    const int32_t* centers[CHB_FUSED_MAX_OPS];    // level's [B][2] cutout centres (cy, cx), else NULL
+    int32_t B, H, W;
+};
+
+__device__ __forceinline__ uint32_t px_load(const uint8_t* __restrict__ img, int H, int W, int y, int x) {
+    const uint8_t* p = img + ((int64_t)y * W + x) * 3;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
+__device__ __forceinline__ uint32_t px_pointwise(int op, uint32_t v, const FusedOp& o) {
+    uint8_t c[3] = {(uint8_t)(v & 0xff), (uint8_t)((v >> 8) & 0xff), (uint8_t)((v >> 16) & 0xff)};
+    const float factor = o.f[0];
+    const bool clip = !(factor > 0.0f && factor < 1.0f);
+    if (op == CHB_AUG_INVERT) {
+        for (int k = 0; k < 3; ++k) c[k] = 255 - c[k];
+    } else if (op == CHB_AUG_POSTERIZE) {
+        for (int k = 0; k < 3; ++k) c[k] = (uint8_t)((c[k] >> o.i0) << o.i0);
+    } else if (op == CHB_AUG_SOLARIZE) {
+        for (int k = 0; k < 3; ++k) c[k] = ((int)c[k] < o.i0) ? c[k] : (uint8_t)(255 - c[k]);
+    } else if (op == CHB_AUG_SOLARIZE_ADD) {
+        for (int k = 0; k < 3; ++k) {
+            int t = (int)c[k] + o.i1;
+            t = t < 0 ? 0 : (t > 255 ? 255 : t);
+            c[k] = ((int)c[k] < o.i0) ? (uint8_t)t : c[k];
+        }
+    } else if (op == CHB_AUG_BRIGHTNESS) {
+        for (int k = 0; k < 3; ++k) c[k] = blend_rt(0, c[k], factor, clip);
+    } else if (op == CHB_AUG_CONTRAST) {
+        for (int k = 0; k < 3; ++k) c[k] = blend_rt((uint8_t)o.i0, c[k], factor, clip);
+    } else if (op == CHB_AUG_COLOR) {
+        const uint8_t d = gray_u8(c[0], c[1], c[2]);
+        for (int k = 0; k < 3; ++k) c[k] = blend_rt(d, c[k], factor, clip);
+    }
+    return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+}
+
+template <int L>
+struct FusedEval {
+    static __device__ uint32_t at(const FusedParams& P, const uint8_t* __restrict__ img, int n, int y, int x) {
+        const FusedOp& o = P.ops[L];
+        const int op = o.op;     // the same for every thread of the launch
+        if (op == CHB_AUG_IDENTITY) return FusedEval<L - 1>::at(P, img, n, y, x);
+        if (op == CHB_AUG_AFFINE) {
+            const float fx = (float)x, fy = (float)y;
+            const float ix = (o.f[0] * fx + o.f[1] * fy) + o.f[2];
+            const float iy = (o.f[3] * fx + o.f[4] * fy) + o.f[5];
+            const float rx = roundf(ix), ry = roundf(iy);
+            const bool ok = (rx >= 0.0f) && (rx < (float)P.W) && (ry >= 0.0f) && (ry < (float)P.H);
+            if (!ok) return ((uint32_t)(o.i0 & 0xff)) * 0x010101u;
+            return FusedEval<L - 1>::at(P, img, n, (int)ry, (int)rx);
+        }
+        if (op == CHB_AUG_CUTOUT) {
+            const int cy = P.centers[L][2 * n], cx = P.centers[L][2 * n + 1];
+            const bool inside = (y >= max(0, cy - o.i2)) && (y < min(P.H, cy + o.i2)) && (x >= max(0, cx - o.i2)) && (x < min(P.W, cx + o.i2));
+            if (inside) return ((uint32_t)(o.i3 & 0xff)) * 0x010101u;
+            return FusedEval<L - 1>::at(P, img, n, y, x);
+        }
+        if (op == CHB_AUG_SHARPNESS) {
+            const uint32_t centre = FusedEval<L - 1>::at(P, img, n, y, x);
+            const bool interior = (y >= 1) && (y < P.H - 1) && (x >= 1) && (x < P.W - 1);
+            const float factor = o.f[0];
+            const bool clip = !(factor > 0.0f && factor < 1.0f);
+            uint32_t deg = centre;
+            if (interior) {
+                const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+                float acc[3] = {0.0f, 0.0f, 0.0f};
+                for (int ky = -1; ky <= 1; ++ky)
+                    for (int kx = -1; kx <= 1; ++kx) {
+                        const uint32_t v = (ky == 0 && kx == 0) ? centre : FusedEval<L - 1>::at(P, img, n, y + ky, x + kx);
+                        const float w = (ky == 0 && kx == 0) ? k5 : k1;
+                        acc[0] = acc[0] + (float)(v & 0xff) * w;
+                        acc[1] = acc[1] + (float)((v >> 8) & 0xff) * w;
+                        acc[2] = acc[2] + (float)((v >> 16) & 0xff) * w;
+                    }
+                deg = (uint32_t)trunc_u8(acc[0]) | ((uint32_t)trunc_u8(acc[1]) << 8) | ((uint32_t)trunc_u8(acc[2]) << 16);
+            }
+            if (factor == 0.0f) return deg;
+            uint32_t out = 0;
+            for (int k = 0; k < 3; ++k)
+                out |= (uint32_t)blend_rt((uint8_t)((deg >> (8 * k)) & 0xff), (uint8_t)((centre >> (8 * k)) & 0xff), factor, clip) << (8 * k);
+            return out;
+        }
+        const uint32_t v = FusedEval<L - 1>::at(P, img, n, y, x);
+        if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
+            const int32_t* lut = P.lut[L] + (int64_t)n * 768;
+            return (uint32_t)(lut[v & 0xff] & 0xff) | ((uint32_t)(lut[256 + ((v >> 8) & 0xff)] & 0xff) << 8) |
+                   ((uint32_t)(lut[512 + ((v >> 16) & 0xff)] & 0xff) << 16);
+        }
+        return px_pointwise(op, v, o);
+    }
+};
+template <>
+struct FusedEval<-1> {
+    static __device__ __forceinline__ uint32_t at(const FusedParams& P, const uint8_t* __restrict__ img, int n, int y, int x) {
+        return px_load(img, P.H, P.W, y, x);
+    }
+};
+
+// histogram of level NLEV-1 (the input of the table op at level NLEV); grid = (pixel slices, B)
+template <int NLEV>
+__global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ ws, FusedParams P) {
+    __shared__ int32_t h[768];
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int n = blockIdx.y;
+    const uint8_t* img = in + (int64_t)n * P.H * P.W * 3;
+    const int HW = P.H * P.W;
+    for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < HW; px += gridDim.x * blockDim.x) {
+        const int y = px / P.W, x = px - y * P.W;
+        const uint32_t v = FusedEval<NLEV - 1>::at(P, img, n, y, x);
+        atomicAdd(&h[v & 0xff], 1);
+        atomicAdd(&h[256 + ((v >> 8) & 0xff)], 1);
+        atomicAdd(&h[512 + ((v >> 16) & 0xff)], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += blockDim.x)
+        if (h[i]) atomicAdd(&ws[(int64_t)n * 768 + i], h[i]);
+}
+
+// final pass: one thread = 4 consecutive pixels of a row.  PATCH: "tf" normalisation + bf16 patch rows (P % 4 == 0), else uint8 NHWC
+template <int NLEV, bool PATCH>
+__global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw) {
+    const int wq = PATCH ? (gw * patch) >> 2 : (P.W + 3) >> 2;
+    const int hh = PATCH ? gh * patch : P.H;
+    const int64_t total = (int64_t)P.B * hh * wq;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(q % wq);
+        const int64_t r = q / wq;
+        const int y = (int)(r % hh);
+        const int n = (int)(r / hh);
+        const int x0 = xq * 4;
+        const uint8_t* img = in + (int64_t)n * P.H * P.W * 3;
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (x0 + i < P.W) ? FusedEval<NLEV - 1>::at(P, img, n, y, x0 + i) : 0u;
+        if (PATCH) {
+            float f[12];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) f[3 * i + c] = norm1<1>((uint8_t)((v[i] >> (8 * c)) & 0xff), c, NormConst{});
+            const int K = patch * patch * 3;
+            const int64_t row = ((int64_t)n * gh + y / patch) * gw + x0 / patch;
+            const int col = ((y % patch) * patch + (x0 % patch)) * 3;
+            uint32_t* d = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(out) + row * K + col);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+        } else {
+            uint8_t* o8 = reinterpret_cast<uint8_t*>(out) + (((int64_t)n * P.H + y) * P.W + x0) * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (x0 + i < P.W) {
+                    o8[3 * i + 0] = (uint8_t)(v[i] & 0xff);
+                    o8[3 * i + 1] = (uint8_t)((v[i] >> 8) & 0xff);
+                    o8[3 * i + 2] = (uint8_t)((v[i] >> 16) & 0xff);
+                }
+        }
+    }
+}
+
+// table from the histogram of one (image, channel): the batch-shared op of level `lvl` (same code as lut_build_kernel)
+__global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ ws, int op) {
+    __shared__ int32_t s[256];
+    __shared__ int32_t first_nz, last_nz;
+    int32_t* h = ws + (int64_t)blockIdx.x * 256;
+    const int t = threadIdx.x;
+    const int32_t mine = h[t];
+    s[t] = mine;
+    if (t == 0) { first_nz = 255; last_nz = 0; }
+    __syncthreads();
+    if (mine != 0) { atomicMax(&last_nz, t); atomicMin(&first_nz, t); }
+    __syncthreads();
+    int32_t lut = t;
+    if (op == CHB_AUG_AUTOCONTRAST) {
+        const float lo = (float)first_nz, hi = (float)last_nz;
+        const float rng = hi - lo;
+        float sc = (rng != 0.0f) ? 255.0f / rng : 0.0f;
+        float of = (-lo) * sc;
+        const float mask = hi > lo ? 1.0f : 0.0f;
+        sc = sc * mask + (1.0f - mask);
+        of = of * mask;
+        float v = (float)t * sc;
+        v = v + of;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        lut = (int32_t)trunc_u8(v);
+    } else {
+        for (int o = 1; o < 256; o <<= 1) {
+            const int32_t v = (t >= o) ? s[t - o] : 0;
+            __syncthreads();
+            s[t] += v;
+            __syncthreads();
+        }
+        const int32_t total = s[255];
+        const int32_t excl = s[t] - mine;
+        const int32_t step = (total - h[last_nz]) / 255;
+        __syncthreads();
+        if (step != 0) {
+            lut = (excl + step / 2) / step;
+            lut = lut < 0 ? 0 : (lut > 255 ? 255 : lut);
+        }
+    }
+    h[t] = lut;
+}
+
 const NormConst kCaffe = {{103.939f, 116.779f, 123.68f}, {1.f, 1.f, 1.f}};
 const NormConst kTorch = {{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};
 
@@ -1284,6 +1508,72 @@ int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const
     const bool fast = (W & 3) == 0 && !((uintptr_t)in & 3) && !((uintptr_t)out & 3);
     if (fast) hipLaunchKernelGGL(aug_dispatch_kernel<true>, grid, dim3(256), 0, s, in, out, B, H, W, items, workspace);
     else hipLaunchKernelGGL(aug_dispatch_kernel<false>, grid, dim3(256), 0, s, in, out, B, H, W, items, workspace);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* ops_host, const int32_t* const* centers_dev,
+                  int32_t* workspace, int patch, void* stream) {
+    if (B == 0) return CHB_OK;
+    if (!in || !out || !ops_host || B < 0 || H <= 0 || W <= 0 || n_ops < 1 || n_ops > CHB_FUSED_MAX_OPS || patch < 0 || (patch & 3)) return CHB_EINVAL;
+    if ((int64_t)H * W * 3 >= 2147483647LL || B > 65535) return CHB_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    FusedParams P;
+    memset(&P, 0, sizeof(P));
+    P.n = n_ops; P.B = B; P.H = H; P.W = W;
+    memcpy(P.ops, ops_host, sizeof(FusedOp) * n_ops);
+    int n_tables = 0;
+    for (int l = 0; l < n_ops; ++l) {
+        const int op = P.ops[l].op;
+        if (op < CHB_AUG_IDENTITY || op > CHB_AUG_CUTOUT) return CHB_EINVAL;
+        if (op == CHB_AUG_CUTOUT) {
+            if (!centers_dev || !centers_dev[l]) return CHB_EINVAL;
+            P.centers[l] = centers_dev[l];
+        }
+        if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
+            if (!workspace) return CHB_EINVAL;
+            P.lut[l] = workspace + (int64_t)n_tables * B * 768;
+            ++n_tables;
+        }
+    }
+    // table ops, in chain order: histogram of the level below (evaluated through everything under it), then the table
+    for (int l = 0; l < n_ops; ++l) {
+        if (!P.lut[l]) continue;
+        int32_t* ws = const_cast<int32_t*>(P.lut[l]);
+        const int nws = B * 768;
+        hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, ws, nws, 1);
+        const int sl = slices_for((int64_t)H * W * 12, B);
+        const dim3 grid(sl, B);
+        switch (l) {
+            case 0: hipLaunchKernelGGL(fused_hist_kernel<0>, grid, dim3(256), 0, s, in, ws, P); break;
+            case 1: hipLaunchKernelGGL(fused_hist_kernel<1>, grid, dim3(256), 0, s, in, ws, P); break;
+            case 2: hipLaunchKernelGGL(fused_hist_kernel<2>, grid, dim3(256), 0, s, in, ws, P); break;
+            default: hipLaunchKernelGGL(fused_hist_kernel<3>, grid, dim3(256), 0, s, in, ws, P); break;
+        }
+        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, ws, P.ops[l].op);
+    }
+    int gh = 0, gw = 0;
+    int64_t total;
+    if (patch) {
+        gh = H / patch; gw = W / patch;
+        if (gh == 0 || gw == 0) return CHB_EINVAL;
+        total = (int64_t)B * gh * patch * ((gw * patch) / 4);
+    } else {
+        total = (int64_t)B * H * ((W + 3) / 4);
+    }
+    const int grid = stream_grid(total);
+#define CHB_FUSED_FINAL(NL)                                                                                                   \
+    do {                                                                                                                      \
+        if (patch) hipLaunchKernelGGL((fused_final_kernel<NL, true>), dim3(grid), dim3(256), 0, s, in, out, P, patch, gh, gw);  \
+        else hipLaunchKernelGGL((fused_final_kernel<NL, false>), dim3(grid), dim3(256), 0, s, in, out, P, patch, gh, gw);       \
+    } while (0)
+    switch (n_ops) {
+        case 1: CHB_FUSED_FINAL(1); break;
+        case 2: CHB_FUSED_FINAL(2); break;
+        case 3: CHB_FUSED_FINAL(3); break;
+        default: CHB_FUSED_FINAL(4); break;
+    }
+#undef CHB_FUSED_FINAL
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

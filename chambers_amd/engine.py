@@ -324,6 +324,12 @@ class GradBucketReducer:
         self.world = dist.get_world_size(process_group) if self.active else 1
         self.handles = []
         self.queued = []
+        # accounting for bench.py's data-parallel report: collectives issued, bytes all-reduced, and (measure=True) HIP-event
+        # pairs around finish()'s waits - the time the compute stream stood still for the exchange
+        self.n_collectives = 0
+        self.bytes_reduced = 0
+        self.measure = False
+        self.exposed_events = []
 
     def bucket_ready(self, k):
         if self.active:
@@ -343,12 +349,27 @@ class GradBucketReducer:
         self.queued = []
         for lo, hi in ranges:
             self.handles.append(self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.n_collectives += 1
+            self.bytes_reduced += (hi - lo) * self.flat.element_size()
 
     def finish(self):
         self.flush()
+        if not self.handles:
+            return
+        timed = self.measure and self.flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self.handles:
             h.wait()
+        if timed:
+            e1.record()
+            self.exposed_events.append((e0, e1))
         self.handles = []
+
+    def exposed_ms(self):
+        """Sum over the recorded finish() calls of the compute stream's wait for the exchange (call after a device synchronise)."""
+        return float(sum(a.elapsed_time(b) for a, b in self.exposed_events))
 
     @property
     def grad_scale(self):
@@ -528,14 +549,21 @@ class ViTEngine:
         step = self.opt_step
         return rate, (lambda site: rng.site_key(self.seed, step, site))
 
-    def embed(self, images_u8, training, prepatched=False):
-        """normalise + patchify + patch-embedding GEMM (+bias +pos, dropout) + cls row -> xs[0]."""
+    def embed(self, images_u8, training, prepatched=False, augment=None):
+        """[scheme chain +] normalise + patchify + patch-embedding GEMM (+bias +pos, dropout) + cls row -> xs[0].
+        augment: a kernels.AugPlan (RandAugment.plan / AutoAugment.plan) applied to images_u8 inside the patchify pass."""
         cfg = self.cfg
         rate, key = self._keys(training)
         if not prepatched:
             if tuple(images_u8.shape) != (self.B, cfg.image_size[0], cfg.image_size[1], 3):
                 raise ValueError("expected images of shape %s, got %s" % ((self.B,) + cfg.image_size + (3,), tuple(images_u8.shape)))
-            K.normalize_patchify(images_u8, cfg.patch_size, cfg.norm_mode, out=self.patches)
+            if augment is not None and len(augment) and cfg.norm_mode == "tf":
+                # scheme chain + normalise + patch gather in one pass over the uint8 batch (chb_aug_fused)
+                K.aug_fused(images_u8, augment, patch=cfg.patch_size, out=self.patches)
+            else:
+                if augment is not None and len(augment):
+                    images_u8 = K.aug_fused(images_u8, augment)
+                K.normalize_patchify(images_u8, cfg.patch_size, cfg.norm_mode, out=self.patches)
         x0 = self.xs[0]
         K.gemm_nt(self.patches, self.wbt("patch_embeddings/embedding/kernel"), x0, m=self.Mpatch,
                   bias=self.p("patch_embeddings/embedding/bias"), epilogue=K.EPI_PATCH, resid=self.p("pos_embedding/embeddings"),
@@ -565,13 +593,13 @@ class ViTEngine:
         K.gemm_nt(a["u"], self.wbt(pre + "dense2/kernel"), x_out, m=M, bias=self.p(pre + "dense2/bias"), epilogue=K.EPI_RESID,
                   resid=a["xmid"], drop_rate=rate, drop_key=key(rng.site_mlp(l)))
 
-    def forward(self, images_u8, training=None, prepatched=False):
+    def forward(self, images_u8, training=None, prepatched=False, augment=None):
         """Returns logits fp32 [B, classes] (a view of the padded logits buffer).  prepatched=True: self.patches
         already holds the bf16 patch rows (float32-input path of the Keras-style Model)."""
         training = self.training if training is None else training
         cfg = self.cfg
         L = cfg.n_encoder_layers
-        x = self.embed(images_u8, training, prepatched)
+        x = self.embed(images_u8, training, prepatched, augment)
         for l in range(L):
             if self.training:
                 x_out, a = self.xs[l + 1], self.acts[l]
@@ -791,12 +819,13 @@ class ViTEngine:
         self._g_clean = bool(zero_grad)
         self.refresh_operands()
 
-    def train_step(self, images_u8, labels, **opt):
-        """augmented uint8 batch -> loss vector; runs forward, loss, backward, gradient exchange, AdamW."""
+    def train_step(self, images_u8, labels, augment=None, **opt):
+        """uint8 batch (already augmented, or raw with the scheme's `augment` plan) -> loss vector; runs forward, loss, backward,
+        gradient exchange, AdamW."""
         if not self.cfg.include_top or self.cfg.distilled:
             raise ValueError("train_step needs a single classification top (include_top=True, not distilled); drive headless and "
                              "distilled models with forward() + backward(doutput) + adamw_step()")
-        self.forward(images_u8, training=True)
+        self.forward(images_u8, training=True, augment=augment)
         loss = self.loss(labels)
         self.backward()
         self.adamw_step(**opt)

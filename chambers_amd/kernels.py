@@ -18,6 +18,13 @@ def _s():
     return _lib.stream_ptr()
 
 
+def _upload(array, device):
+    """Host array -> device tensor through pinned memory, asynchronously on the current stream: a pageable copy would make the
+    host wait for everything already queued on the stream (the previous training step)."""
+    t = torch.from_numpy(np.ascontiguousarray(array))
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _u8_nhwc(x):
     _lib.require_gpu(x)
     if x.dtype != torch.uint8 or x.dim() != 4:
@@ -58,7 +65,7 @@ def aug_cutout(x, centers, mask_size, value=0):
     if int(mask_size) % 2 != 0:
         raise ValueError("mask_size should be divisible by 2")
     if not isinstance(centers, torch.Tensor):
-        centers = torch.as_tensor(np.asarray(centers, dtype=np.int32).reshape(b, 2), device=x.device)
+        centers = _upload(np.asarray(centers, dtype=np.int32).reshape(b, 2), x.device)
     centers = centers.to(torch.int32).contiguous()
     _lib.require_gpu(centers)
     out = torch.empty_like(x)
@@ -116,10 +123,73 @@ def aug_dispatch(x, items, out=None):
     if items.shape != (b,):
         raise ValueError("expected %d op records, got %s" % (b, items.shape))
     n_stats = int(np.isin(items["op"], (_lib.AUG_AUTOCONTRAST, _lib.AUG_EQUALIZE)).sum())
-    dev = torch.as_tensor(items.view(np.uint8).reshape(b, 64), device=x.device)
+    dev = _upload(items.view(np.uint8).reshape(b, 64), x.device)
     ws = torch.empty(max(b * 768, 1), dtype=torch.int32, device=x.device) if n_stats else None
     out = torch.empty_like(x) if out is None else out
     _lib.call("chb_aug_dispatch", _lib.ptr(x), _lib.ptr(out), b, h, w, _lib.ptr(dev), n_stats, _lib.ptr(ws), _s())
+    return out
+
+
+FUSED_OP_DTYPE = np.dtype([("op", np.int32), ("i", np.int32, (4,)), ("f", np.float32, (6,)), ("pad", np.int32)])   # 48 bytes
+FUSED_MAX_OPS = 4
+
+
+class AugPlan:
+    """The batch-shared decisions of one scheme call, resolved to op records: what chb_aug_fused evaluates per pixel.
+    items: AUG_ITEM_DTYPE records in application order; centers: per level None or int32 [B,2] (CutOut's per-image centres)."""
+
+    def __init__(self, items, centers=None):
+        self.items = list(items)
+        self.centers = list(centers) if centers is not None else [None] * len(self.items)
+        if len(self.centers) != len(self.items):
+            raise ValueError("one centres entry per op")
+
+    def __len__(self):
+        return len(self.items)
+
+    @property
+    def n_tables(self):
+        return sum(int(it["op"]) in (_lib.AUG_AUTOCONTRAST, _lib.AUG_EQUALIZE) for it in self.items)
+
+
+def aug_fused(x, plan, patch=None, out=None):
+    """One launch for a whole batch-shared op chain (plus one histogram pass per AutoContrast / Equalize in it).
+    patch=None: uint8 NHWC result;  patch=P: bf16 patch rows of the "tf"-normalised result (normalize_patchify fused in)."""
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    if c != 3:
+        raise ValueError("the fused scheme stage handles RGB batches (the schemes' InputSpec), got %d channels" % c)
+    n = len(plan)
+    if not 1 <= n <= FUSED_MAX_OPS:
+        raise ValueError("a fused chain holds 1..%d ops, got %d" % (FUSED_MAX_OPS, n))
+    recs = np.zeros(n, dtype=FUSED_OP_DTYPE)
+    cptr = (ctypes.c_void_p * n)()
+    keep = []
+    for l, it in enumerate(plan.items):
+        recs[l]["op"] = it["op"]
+        recs[l]["i"] = it["i"]
+        recs[l]["f"] = it["f"][:6]
+        if int(it["op"]) == _lib.AUG_CUTOUT:
+            cen = np.ascontiguousarray(plan.centers[l], dtype=np.int32)
+            if cen.shape != (b, 2):
+                raise ValueError("CutOut wants one (cy, cx) per image: expected %s, got %s" % ((b, 2), cen.shape))
+            dev = _upload(cen, x.device)
+            keep.append(dev)
+            cptr[l] = dev.data_ptr()
+    nt = plan.n_tables
+    ws = torch.empty(nt * b * 768, dtype=torch.int32, device=x.device) if nt and b else None
+    if patch is None:
+        out = torch.empty_like(x) if out is None else out
+        if out.shape != x.shape or out.dtype != torch.uint8 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous uint8 tensor shaped like the input")
+    else:
+        rows = b * (h // patch) * (w // patch)
+        if out is None:
+            out = torch.empty((rows, patch * patch * 3), dtype=torch.bfloat16, device=x.device)
+        if out.dtype != torch.bfloat16 or out.numel() < rows * patch * patch * 3 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous bf16 buffer of at least %d patch rows" % rows)
+    _lib.call("chb_aug_fused", _lib.ptr(x), _lib.ptr(out), b, h, w, n, recs.ctypes.data, ctypes.cast(cptr, ctypes.c_void_p),
+              _lib.ptr(ws), 0 if patch is None else int(patch), _s())
     return out
 
 

@@ -289,6 +289,20 @@ int chb_adamw(float* p, float* g, float* m, float* v, const uint8_t* decay_flags
 int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const void* items_dev, int n_stats,
                      int32_t* workspace, void* stream);
 
+/* Fused scheme stage for BATCH-SHARED decisions (RandAugment.call augmentation_schemes.py:204-213, AutoAugment :151-160; then
+ * ImageNetNormalization("tf") image_augmentations.py:659-665 and the patch gather of vision_transformer.py:235-248): the chain
+ * of n_ops <= CHB_FUSED_MAX_OPS ops is evaluated per output pixel in ONE pass over the batch.  ops_host: n_ops HOST records
+ *   struct { int32 op; int32 i0, i1, i2, i3; float f[6]; int32 pad; }    (48 bytes; op = CHB_AUG_*, fields as for chb_aug_dispatch;
+ *   Contrast's i0 is the constant of the whole batch tensor, B*H*W/256 clipped), applied in order.
+ * centers_dev[l]: device int32 [B,2] (cy, cx) for a CutOut at level l (else ignored / NULL).  workspace: int32 [n_tables*B*768]
+ * when the chain holds AutoContrast / Equalize (each costs a histogram pass of the level below it + a table launch).
+ * patch == 0: out = uint8 NHWC [B,H,W,3] (the chain's image);  patch > 0 (multiple of 4): out = bf16 [B*(H/patch)*(W/patch),
+ * patch*patch*3] patch rows of the "tf"-normalised chain output (what chb_normalize_patchify_bf16 would produce from it).
+ * Bit-identical to running the ops one after the other. */
+#define CHB_FUSED_MAX_OPS 4
+int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* ops_host,
+                  const int32_t* const* centers_dev, int32_t* workspace, int patch, void* stream);
+
 /* Tuning / A-B switch `name` (ATTN_FWD_ALGO, ATTN_BWD_ALGO, AFFINE_ALGO, GEMM_ALGO, GEMM_WALK, TN_ATOMICS, TN_FAST,
  * GEMM_EPI_OVERLAP; csrc/common.hpp) := value.  Defaults come from the environment variables CHB_<name>, read once per
  * process; nothing on the launch path calls getenv.  Results are identical under every setting (the parity tests

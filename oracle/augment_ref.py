@@ -164,12 +164,18 @@ def equalize(x):
     return out
 
 
-def sharpness(x, factor):
+def sharpness(x, factor, final_cast="truncate"):
     """Sharpness.call -> tfa.image.sharpness (upstream restated,
-    tensorflow_addons image/filters.py? color_ops.py `sharpness_image`): depthwise
+    tensorflow_addons image/color_ops.py `sharpness_image`): depthwise
     3x3 [[1,1,1],[1,5,1],[1,1,1]]/13 VALID in f32 (accumulated row-major, no
     FMA), truncated to uint8; the 1-pixel border keeps the original; then
-    blend(degenerate, original, factor) with clip and truncating cast."""
+    blend(degenerate, original, factor) with clip and truncating cast.
+
+    OPEN CHOICE (parity unpinned, tensorflow-addons is not pinned in requirements.txt:3): the final blend goes through TFA's own
+    `blend` (tensorflow_addons/image/compose_ops.py), not chambers' (image_augmentations.py:10-49).  SURVEY 8a row 24 restates
+    it with a truncating cast, which is what this oracle and the HIP kernel implement (``final_cast="truncate"``); another
+    recollection of that file has `tf.round` in front of the cast.  ``final_cast="round"`` evaluates that alternative so the
+    known-answer test (tests/test_oracle_kat.py::test_sharpness_final_cast_is_an_open_choice) shows where the two differ."""
     b, h, w, c = x.shape
     xf = x.astype(F32)
     k = (np.array([[1, 1, 1], [1, 5, 1], [1, 1, 1]], dtype=F32) / F32(13.0)).astype(F32)
@@ -188,6 +194,10 @@ def sharpness(x, factor):
     temp = i1 + F32(factor) * (xf - i1)
     if not (0.0 <= factor <= 1.0):
         temp = np.clip(temp, F32(0.0), F32(255.0))
+    if final_cast == "round":
+        temp = np.rint(temp)        # tf.round: half to even
+    elif final_cast != "truncate":
+        raise ValueError(final_cast)
     return _trunc_u8(temp)
 
 

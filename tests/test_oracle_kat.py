@@ -133,3 +133,21 @@ def test_magnitude_maps_match_reference_table():
     assert abs(A.magnitude_to_kwargs("Rotate", 9)["degrees"] - 27.0) < 1e-12
     assert A.magnitude_to_kwargs("Posterize", 2)["bits"] == 0 and A.magnitude_to_kwargs("Solarize", 10)["threshold"] == 256
     assert len(A.AUTO_AUGMENT_POLICY_V0) == 25 and len(A.RANDAUGMENT_OPS) == 16
+
+
+def test_sharpness_final_cast_is_an_open_choice():
+    """Builder-derived KAT that separates the two candidate roundings of tfa.image.sharpness's final blend (DESIGN.md section 2,
+    open choices): on a 3x3 image whose centre is 10 among 200s the smoothed centre is trunc((8*200 + 5*10)/13) = 126, and
+    blend(126, 10, 1.72) = 126 + 1.72*(10 - 126) = -73.52 -> clipped to 0 (both agree); with centre 101 the blend is
+    161 + 1.72*(101 - 161) = 57.8: truncation (the oracle and the HIP kernel) gives 57, tf.round gives 58."""
+    x = np.full((1, 3, 3, 3), 200, dtype=np.uint8)
+    x[0, 1, 1] = 101
+    smoothed = int((np.float32(8 * 200) + np.float32(5 * 101)) / np.float32(13))      # ~161.9 -> 161
+    assert smoothed == 161
+    t = A.sharpness(x, 1.72)
+    r = A.sharpness(x, 1.72, final_cast="round")
+    assert int(t[0, 1, 1, 0]) == 57 and int(r[0, 1, 1, 0]) == 58
+    border = np.ones((3, 3), bool)
+    border[1, 1] = False
+    assert (t[0][border] == 200).all() and (r[0][border] == 200).all()          # the 1-pixel border keeps the original
+    assert (A.sharpness(x, 0.4) == A.sharpness(x, 0.4, final_cast="truncate")).all()
