@@ -33,7 +33,7 @@ PROTOTYPES = {
     "chb_aug_equalize": [P, P, c_int, c_int, c_int, c_int, P, P],
     "chb_aug_sharpness": [P, P, c_int, c_int, c_int, c_int, c_float, P],
     "chb_aug_dispatch": [P, P, c_int, c_int, c_int, P, c_int, P, P],
-    "chb_aug_fused": [P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P],
+    "chb_aug_fused": [P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P],
     "chb_normalize_u8": [P, P, c_int64, c_int, c_int, P],
     "chb_normalize_f32": [P, P, c_int64, c_int, c_int, P],
     "chb_normalize_patchify_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, P],

@@ -426,7 +426,8 @@ def batch_item(transform, batch, height, width, **kwargs):
         if centers is None:
             g = rng.host_generator()
             centers = np.stack([g.integers(0, height, size=batch), g.integers(0, width, size=batch)], axis=1)
-        centers = np.ascontiguousarray(centers, dtype=np.int32).reshape(batch, 2)
+        if not isinstance(centers, torch.Tensor):        # a device tensor = resident decisions, used as they are
+            centers = np.ascontiguousarray(centers, dtype=np.int32).reshape(batch, 2)
         return transform.dispatch_item(height, width, centers=(0, 0)), centers
     return transform.dispatch_item(height, width, **kwargs), None
 

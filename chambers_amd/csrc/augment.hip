@@ -1173,158 +1173,327 @@ struct FusedParams {
     int32_t B, H, W;
 };
 
+// one unaligned dword per pixel (the memory pipeline, not HBM, bounds the gathers: a byte load costs what a dword load costs);
+// the last pixel of the image steps back a byte instead of reading past the allocation (a one-pixel image loads bytes)
 __device__ __forceinline__ uint32_t px_load(const uint8_t* __restrict__ img, int H, int W, int y, int x) {
-    const uint8_t* p = img + ((int64_t)y * W + x) * 3;
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    const int off = (y * W + x) * 3;
+    const int end = H * W * 3;
+    if (off + 4 <= end) return reinterpret_cast<const u32_unaligned*>(img + off)->v & 0xffffffu;
+    if (off >= 1) return reinterpret_cast<const u32_unaligned*>(img + off - 1)->v >> 8;
+    return (uint32_t)img[off] | ((uint32_t)img[off + 1] << 8) | ((uint32_t)img[off + 2] << 16);
 }
+
+struct FusedCtx {
+    const uint8_t* img;      // this image, level -1
+    const uint8_t* lut;      // LDS: [level][3][256] tables of the table ops of this segment
+    int n;                   // image index (cutout centres)
+    bool fast;               // W % 4 == 0 and 4-byte aligned rows: 12-byte quad loads
+};
 
 __device__ __forceinline__ uint32_t px_pointwise(int op, uint32_t v, const FusedOp& o) {
     uint8_t c[3] = {(uint8_t)(v & 0xff), (uint8_t)((v >> 8) & 0xff), (uint8_t)((v >> 16) & 0xff)};
     const float factor = o.f[0];
     const bool clip = !(factor > 0.0f && factor < 1.0f);
-    if (op == CHB_AUG_INVERT) {
-        for (int k = 0; k < 3; ++k) c[k] = 255 - c[k];
-    } else if (op == CHB_AUG_POSTERIZE) {
-        for (int k = 0; k < 3; ++k) c[k] = (uint8_t)((c[k] >> o.i0) << o.i0);
-    } else if (op == CHB_AUG_SOLARIZE) {
-        for (int k = 0; k < 3; ++k) c[k] = ((int)c[k] < o.i0) ? c[k] : (uint8_t)(255 - c[k]);
-    } else if (op == CHB_AUG_SOLARIZE_ADD) {
-        for (int k = 0; k < 3; ++k) {
-            int t = (int)c[k] + o.i1;
-            t = t < 0 ? 0 : (t > 255 ? 255 : t);
-            c[k] = ((int)c[k] < o.i0) ? (uint8_t)t : c[k];
+    switch (op) {
+        case CHB_AUG_INVERT:
+            for (int k = 0; k < 3; ++k) c[k] = 255 - c[k];
+            break;
+        case CHB_AUG_POSTERIZE:
+            for (int k = 0; k < 3; ++k) c[k] = (uint8_t)((c[k] >> o.i0) << o.i0);
+            break;
+        case CHB_AUG_SOLARIZE:
+            for (int k = 0; k < 3; ++k) c[k] = ((int)c[k] < o.i0) ? c[k] : (uint8_t)(255 - c[k]);
+            break;
+        case CHB_AUG_SOLARIZE_ADD:
+            for (int k = 0; k < 3; ++k) {
+                int t = (int)c[k] + o.i1;
+                t = t < 0 ? 0 : (t > 255 ? 255 : t);
+                c[k] = ((int)c[k] < o.i0) ? (uint8_t)t : c[k];
+            }
+            break;
+        case CHB_AUG_BRIGHTNESS:
+            for (int k = 0; k < 3; ++k) c[k] = blend_rt(0, c[k], factor, clip);
+            break;
+        case CHB_AUG_CONTRAST:
+            for (int k = 0; k < 3; ++k) c[k] = blend_rt((uint8_t)o.i0, c[k], factor, clip);
+            break;
+        case CHB_AUG_COLOR: {
+            const uint8_t d = gray_u8(c[0], c[1], c[2]);
+            for (int k = 0; k < 3; ++k) c[k] = blend_rt(d, c[k], factor, clip);
+            break;
         }
-    } else if (op == CHB_AUG_BRIGHTNESS) {
-        for (int k = 0; k < 3; ++k) c[k] = blend_rt(0, c[k], factor, clip);
-    } else if (op == CHB_AUG_CONTRAST) {
-        for (int k = 0; k < 3; ++k) c[k] = blend_rt((uint8_t)o.i0, c[k], factor, clip);
-    } else if (op == CHB_AUG_COLOR) {
-        const uint8_t d = gray_u8(c[0], c[1], c[2]);
-        for (int k = 0; k < 3; ++k) c[k] = blend_rt(d, c[k], factor, clip);
+        default: break;
     }
     return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
 }
 
+__device__ __forceinline__ void quad_pointwise(int op, uint8_t (&b)[12], const FusedOp& o) {
+    const PwParams pp{0, o.f[0], o.i0, o.i1};
+    switch (op) {   // uniform over the launch
+        case CHB_AUG_INVERT: pointwise12<CHB_PW_INVERT>(b, pp); break;
+        case CHB_AUG_POSTERIZE: pointwise12<CHB_PW_POSTERIZE>(b, pp); break;
+        case CHB_AUG_SOLARIZE: pointwise12<CHB_PW_SOLARIZE>(b, pp); break;
+        case CHB_AUG_SOLARIZE_ADD: pointwise12<CHB_PW_SOLARIZE_ADD>(b, pp); break;
+        case CHB_AUG_BRIGHTNESS: pointwise12<CHB_PW_BRIGHTNESS>(b, pp); break;
+        case CHB_AUG_CONTRAST: pointwise12<CHB_PW_CONTRAST>(b, pp); break;
+        case CHB_AUG_COLOR: pointwise12<CHB_PW_COLOR>(b, pp); break;
+        default: break;
+    }
+}
+
+__device__ __forceinline__ bool affine_source(const FusedOp& o, int W, int H, int x, int y, int& sx, int& sy) {
+    const float fx = (float)x, fy = (float)y;
+    const float ix = (o.f[0] * fx + o.f[1] * fy) + o.f[2];
+    const float iy = (o.f[3] * fx + o.f[4] * fy) + o.f[5];
+    const float rx = roundf(ix), ry = roundf(iy);   // half away from zero
+    const bool ok = (rx >= 0.0f) && (rx < (float)W) && (ry >= 0.0f) && (ry < (float)H);
+    sx = ok ? (int)rx : 0;
+    sy = ok ? (int)ry : 0;
+    return ok;
+}
+
+__device__ __forceinline__ bool cutout_inside(const FusedParams& P, int l, int n, int y, int x) {
+    const int cy = P.centers[l][2 * n], cx = P.centers[l][2 * n + 1], half = P.ops[l].i2;
+    return (y >= max(0, cy - half)) && (y < min(P.H, cy + half)) && (x >= max(0, cx - half)) && (x < min(P.W, cx + half));
+}
+
+// ---- one pixel of level L (gathers: below a warp, and the two edge columns of a Sharpness window) ----
 template <int L>
 struct FusedEval {
-    static __device__ uint32_t at(const FusedParams& P, const uint8_t* __restrict__ img, int n, int y, int x) {
+    static __device__ uint32_t at(const FusedParams& P, const FusedCtx& C, int y, int x) {
         const FusedOp& o = P.ops[L];
         const int op = o.op;     // the same for every thread of the launch
-        if (op == CHB_AUG_IDENTITY) return FusedEval<L - 1>::at(P, img, n, y, x);
-        if (op == CHB_AUG_AFFINE) {
-            const float fx = (float)x, fy = (float)y;
-            const float ix = (o.f[0] * fx + o.f[1] * fy) + o.f[2];
-            const float iy = (o.f[3] * fx + o.f[4] * fy) + o.f[5];
-            const float rx = roundf(ix), ry = roundf(iy);
-            const bool ok = (rx >= 0.0f) && (rx < (float)P.W) && (ry >= 0.0f) && (ry < (float)P.H);
-            if (!ok) return ((uint32_t)(o.i0 & 0xff)) * 0x010101u;
-            return FusedEval<L - 1>::at(P, img, n, (int)ry, (int)rx);
-        }
-        if (op == CHB_AUG_CUTOUT) {
-            const int cy = P.centers[L][2 * n], cx = P.centers[L][2 * n + 1];
-            const bool inside = (y >= max(0, cy - o.i2)) && (y < min(P.H, cy + o.i2)) && (x >= max(0, cx - o.i2)) && (x < min(P.W, cx + o.i2));
-            if (inside) return ((uint32_t)(o.i3 & 0xff)) * 0x010101u;
-            return FusedEval<L - 1>::at(P, img, n, y, x);
-        }
         if (op == CHB_AUG_SHARPNESS) {
-            const uint32_t centre = FusedEval<L - 1>::at(P, img, n, y, x);
             const bool interior = (y >= 1) && (y < P.H - 1) && (x >= 1) && (x < P.W - 1);
             const float factor = o.f[0];
             const bool clip = !(factor > 0.0f && factor < 1.0f);
-            uint32_t deg = centre;
-            if (interior) {
-                const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
-                float acc[3] = {0.0f, 0.0f, 0.0f};
-                for (int ky = -1; ky <= 1; ++ky)
-                    for (int kx = -1; kx <= 1; ++kx) {
-                        const uint32_t v = (ky == 0 && kx == 0) ? centre : FusedEval<L - 1>::at(P, img, n, y + ky, x + kx);
-                        const float w = (ky == 0 && kx == 0) ? k5 : k1;
-                        acc[0] = acc[0] + (float)(v & 0xff) * w;
-                        acc[1] = acc[1] + (float)((v >> 8) & 0xff) * w;
-                        acc[2] = acc[2] + (float)((v >> 16) & 0xff) * w;
-                    }
-                deg = (uint32_t)trunc_u8(acc[0]) | ((uint32_t)trunc_u8(acc[1]) << 8) | ((uint32_t)trunc_u8(acc[2]) << 16);
+            const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+            float acc[3] = {0.0f, 0.0f, 0.0f};
+            uint32_t centre = 0;
+#pragma unroll 1
+            for (int t = interior ? 0 : 4; t < (interior ? 9 : 5); ++t) {      // row-major taps; a border pixel reads its centre only
+                const int ky = t / 3 - 1, kx = t % 3 - 1;
+                const uint32_t v = FusedEval<L - 1>::at(P, C, y + ky, x + kx);
+                const float w = (t == 4) ? k5 : k1;
+                if (t == 4) centre = v;
+                acc[0] = acc[0] + (float)(v & 0xff) * w;
+                acc[1] = acc[1] + (float)((v >> 8) & 0xff) * w;
+                acc[2] = acc[2] + (float)((v >> 16) & 0xff) * w;
             }
+            uint32_t deg = centre;
+            if (interior) deg = (uint32_t)trunc_u8(acc[0]) | ((uint32_t)trunc_u8(acc[1]) << 8) | ((uint32_t)trunc_u8(acc[2]) << 16);
             if (factor == 0.0f) return deg;
             uint32_t out = 0;
             for (int k = 0; k < 3; ++k)
                 out |= (uint32_t)blend_rt((uint8_t)((deg >> (8 * k)) & 0xff), (uint8_t)((centre >> (8 * k)) & 0xff), factor, clip) << (8 * k);
             return out;
         }
-        const uint32_t v = FusedEval<L - 1>::at(P, img, n, y, x);
+        int sx = x, sy = y;
+        bool keep = true;            // false: the level's constant replaces the pixel
+        uint32_t konst = 0;
+        if (op == CHB_AUG_AFFINE) {
+            keep = affine_source(o, P.W, P.H, x, y, sx, sy);
+            konst = ((uint32_t)(o.i0 & 0xff)) * 0x010101u;
+        } else if (op == CHB_AUG_CUTOUT) {
+            keep = !cutout_inside(P, L, C.n, y, x);
+            konst = ((uint32_t)(o.i3 & 0xff)) * 0x010101u;
+        }
+        const uint32_t v = FusedEval<L - 1>::at(P, C, sy, sx);
+        if (!keep) return konst;
         if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
-            const int32_t* lut = P.lut[L] + (int64_t)n * 768;
-            return (uint32_t)(lut[v & 0xff] & 0xff) | ((uint32_t)(lut[256 + ((v >> 8) & 0xff)] & 0xff) << 8) |
-                   ((uint32_t)(lut[512 + ((v >> 16) & 0xff)] & 0xff) << 16);
+            const uint8_t* lut = C.lut + L * 768;
+            return (uint32_t)lut[v & 0xff] | ((uint32_t)lut[256 + ((v >> 8) & 0xff)] << 8) | ((uint32_t)lut[512 + ((v >> 16) & 0xff)] << 16);
         }
         return px_pointwise(op, v, o);
     }
 };
 template <>
 struct FusedEval<-1> {
-    static __device__ __forceinline__ uint32_t at(const FusedParams& P, const uint8_t* __restrict__ img, int n, int y, int x) {
-        return px_load(img, P.H, P.W, y, x);
+    static __device__ __forceinline__ uint32_t at(const FusedParams& P, const FusedCtx& C, int y, int x) {
+        return px_load(C.img, P.H, P.W, y, x);
     }
 };
 
-// histogram of level NLEV-1 (the input of the table op at level NLEV); grid = (pixel slices, B)
-template <int NLEV>
-__global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ ws, FusedParams P) {
-    __shared__ int32_t h[768];
-    for (int i = threadIdx.x; i < 768; i += blockDim.x) h[i] = 0;
+// ---- four consecutive pixels (x0 % 4 == 0) of row y at level L; pixels at x >= W come back as anything and are never used ----
+// LOCAL: the launch holds no warp and no Sharpness (the host checked): a level reads only its own pixel, and the gather code is
+// compiled out (a third of the registers: twice the waves in flight)
+template <int L, bool LOCAL>
+struct FusedQuad {
+    static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
+        const FusedOp& o = P.ops[L];
+        const int op = o.op;
+        if (!LOCAL && op == CHB_AUG_AFFINE) {
+            const uint32_t fillw = ((uint32_t)(o.i0 & 0xff)) * 0x010101u;
+#pragma unroll      // the four gathers in flight together
+            for (int i = 0; i < 4; ++i) {
+                int sx, sy;
+                const bool ok = affine_source(o, P.W, P.H, x0 + i, y, sx, sy);
+                uint32_t v = FusedEval<L - 1>::at(P, C, sy, sx);
+                v = ok ? v : fillw;
+                b[3 * i + 0] = v & 0xff; b[3 * i + 1] = (v >> 8) & 0xff; b[3 * i + 2] = (v >> 16) & 0xff;
+            }
+            return;
+        }
+        if (!LOCAL && op == CHB_AUG_SHARPNESS) {
+            // window rows y-1..y+1, columns x0-1..x0+4: three quads + the two edge columns, 18 evaluations for 4 outputs; the
+            // taps are summed in row-major order, so the rows can be folded into the 12 sums as they arrive
+            const bool yin = (y >= 1) && (y < P.H - 1);
+            const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+            float acc[12];
+            uint8_t orig[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { acc[i] = 0.0f; orig[i] = 0; }
+#pragma unroll 1
+            for (int r = yin ? 0 : 1; r < (yin ? 3 : 2); ++r) {
+                uint8_t w[18];
+                uint8_t q[12];
+                FusedQuad<L - 1, LOCAL>::at(P, C, y + r - 1, x0, q);
+                const uint32_t lft = (yin && x0 >= 1) ? FusedEval<L - 1>::at(P, C, y + r - 1, x0 - 1) : 0u;
+                const uint32_t rgt = (yin && x0 + 4 < P.W) ? FusedEval<L - 1>::at(P, C, y + r - 1, x0 + 4) : 0u;
+                w[0] = lft & 0xff; w[1] = (lft >> 8) & 0xff; w[2] = (lft >> 16) & 0xff;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) w[3 + i] = q[i];
+                w[15] = rgt & 0xff; w[16] = (rgt >> 8) & 0xff; w[17] = (rgt >> 16) & 0xff;
+                const float kmid = (r == 1) ? k5 : k1;
+                if (r == 1) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) orig[i] = q[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc[3 * i + c] = acc[3 * i + c] + (float)w[3 * (i + kx) + c] * (kx == 1 ? kmid : k1);
+            }
+            const float factor = o.f[0];
+            const bool clip = !(factor > 0.0f && factor < 1.0f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = x0 + i;
+                const bool interior = yin && (x >= 1) && (x < P.W - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint8_t deg = interior ? trunc_u8(acc[3 * i + c]) : orig[3 * i + c];
+                    b[3 * i + c] = (factor == 0.0f) ? deg : blend_rt(deg, orig[3 * i + c], factor, clip);
+                }
+            }
+            return;
+        }
+        FusedQuad<L - 1, LOCAL>::at(P, C, y, x0, b);
+        if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
+            const uint8_t* lut = C.lut + L * 768;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
+        } else if (op == CHB_AUG_CUTOUT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool inside = cutout_inside(P, L, C.n, y, x0 + i);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+            }
+        } else {
+            quad_pointwise(op, b, o);
+        }
+    }
+};
+template <bool LOCAL>
+struct FusedQuad<-1, LOCAL> {
+    static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
+        const uint8_t* row = C.img + (int64_t)y * P.W * 3;
+        if (C.fast) load_quad<true>(row, x0, P.W, b);
+        else load_quad<false>(row, x0, P.W, b);
+    }
+};
+
+__device__ __forceinline__ void fused_stage_luts(const FusedParams& P, int n, uint8_t* lutS) {
+    for (int l = 0; l < P.n; ++l)       // uniform
+        if (P.lut[l])
+            for (int i = threadIdx.x; i < 768; i += blockDim.x) lutS[l * 768 + i] = (uint8_t)P.lut[l][(int64_t)n * 768 + i];
     __syncthreads();
+}
+
+// histogram of level NLEV-1 (the input of the table op at level NLEV); grid = (row slices, B)
+template <int NLEV, bool LOCAL>
+__global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ ws, FusedParams P, int fast,
+                                                         int minmax) {
+    __shared__ int32_t h[768];
+    int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+    __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) h[i] = 0;
     const int n = blockIdx.y;
-    const uint8_t* img = in + (int64_t)n * P.H * P.W * 3;
-    const int HW = P.H * P.W;
-    for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < HW; px += gridDim.x * blockDim.x) {
-        const int y = px / P.W, x = px - y * P.W;
-        const uint32_t v = FusedEval<NLEV - 1>::at(P, img, n, y, x);
-        atomicAdd(&h[v & 0xff], 1);
-        atomicAdd(&h[256 + ((v >> 8) & 0xff)], 1);
-        atomicAdd(&h[512 + ((v >> 16) & 0xff)], 1);
+    fused_stage_luts(P, n, lutS);
+    const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
+    const int wq = (P.W + 3) >> 2;
+    const int nq = P.H * wq;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const int y = q / wq, x0 = (q - y * wq) * 4;
+        uint8_t b[12];
+        FusedQuad<NLEV - 1, LOCAL>::at(P, C, y, x0, b);
+        if (minmax) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (x0 + i / 3 < P.W) { lo[i % 3] = min(lo[i % 3], (int)b[i]); hi[i % 3] = max(hi[i % 3], (int)b[i]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (x0 + i / 3 < P.W) atomicAdd(&h[(i % 3) * 256 + b[i]], 1);
+        }
+    }
+    if (minmax) {      // AutoContrast needs the extremes only: slot 0 / 1 of each channel's table hold min / max
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            for (int o = 32; o > 0; o >>= 1) {
+                lo[c] = min(lo[c], __shfl_xor(lo[c], o));
+                hi[c] = max(hi[c], __shfl_xor(hi[c], o));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicMin(&ws[((int64_t)n * 3 + c) * 256], lo[c]);
+                atomicMax(&ws[((int64_t)n * 3 + c) * 256 + 1], hi[c]);
+            }
+        }
+        return;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 768; i += blockDim.x)
         if (h[i]) atomicAdd(&ws[(int64_t)n * 768 + i], h[i]);
 }
 
-// final pass: one thread = 4 consecutive pixels of a row.  PATCH: "tf" normalisation + bf16 patch rows (P % 4 == 0), else uint8 NHWC
-template <int NLEV, bool PATCH>
-__global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw) {
+// final pass: grid = (row groups of 16, B); wave = 4 consecutive rows, lane = 4-pixel quad.
+// PATCH: "tf" normalisation + bf16 patch rows (patch % 4 == 0: a quad never straddles patches), else uint8 NHWC
+template <int NLEV, bool PATCH, bool LOCAL>
+__global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw,
+                                                          int fast) {
+    __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
+    const int n = blockIdx.y;
+    fused_stage_luts(P, n, lutS);
+    const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = PATCH ? (gw * patch) >> 2 : (P.W + 3) >> 2;
     const int hh = PATCH ? gh * patch : P.H;
-    const int64_t total = (int64_t)P.B * hh * wq;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-        const int xq = (int)(q % wq);
-        const int64_t r = q / wq;
-        const int y = (int)(r % hh);
-        const int n = (int)(r / hh);
-        const int x0 = xq * 4;
-        const uint8_t* img = in + (int64_t)n * P.H * P.W * 3;
-        uint32_t v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (x0 + i < P.W) ? FusedEval<NLEV - 1>::at(P, img, n, y, x0 + i) : 0u;
+    const int row0 = blockIdx.x * 16 + wave * 4;
+    const int K = patch * patch * 3;
+    if (row0 >= hh) return;
+    const int nrows = min(4, hh - row0);
+    // the wave's 4 rows x wq quads as one index space: all 64 lanes busy whatever the row length
+    for (int idx = lane; idx < nrows * wq; idx += 64) {
+        const int k = idx / wq, xq = idx - k * wq;
+        const int y = row0 + k, x0 = xq * 4;
+        uint8_t b[12];
+        FusedQuad<NLEV - 1, LOCAL>::at(P, C, y, x0, b);
         if (PATCH) {
             float f[12];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) f[3 * i + c] = norm1<1>((uint8_t)((v[i] >> (8 * c)) & 0xff), c, NormConst{});
-            const int K = patch * patch * 3;
+            for (int i = 0; i < 12; ++i) f[i] = norm1<1>(b[i], i % 3, NormConst{});
             const int64_t row = ((int64_t)n * gh + y / patch) * gw + x0 / patch;
             const int col = ((y % patch) * patch + (x0 % patch)) * 3;
             uint32_t* d = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(out) + row * K + col);
 #pragma unroll
             for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
         } else {
-            uint8_t* o8 = reinterpret_cast<uint8_t*>(out) + (((int64_t)n * P.H + y) * P.W + x0) * 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (x0 + i < P.W) {
-                    o8[3 * i + 0] = (uint8_t)(v[i] & 0xff);
-                    o8[3 * i + 1] = (uint8_t)((v[i] >> 8) & 0xff);
-                    o8[3 * i + 2] = (uint8_t)((v[i] >> 16) & 0xff);
-                }
+            uint8_t* orow = reinterpret_cast<uint8_t*>(out) + ((int64_t)n * P.H + y) * P.W * 3;
+            if (C.fast) store_quad<true>(orow, x0, P.W, b);
+            else store_quad<false>(orow, x0, P.W, b);
         }
     }
 }
@@ -1343,7 +1512,7 @@ __global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ ws
     __syncthreads();
     int32_t lut = t;
     if (op == CHB_AUG_AUTOCONTRAST) {
-        const float lo = (float)first_nz, hi = (float)last_nz;
+        const float lo = (float)s[0], hi = (float)s[1];      // the statistics pass left min / max in slots 0 / 1
         const float rng = hi - lo;
         float sc = (rng != 0.0f) ? 255.0f / rng : 0.0f;
         float of = (-lo) * sc;
@@ -1512,60 +1681,57 @@ int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const
     return CHB_OK;
 }
 
-int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* ops_host, const int32_t* const* centers_dev,
-                  int32_t* workspace, int patch, void* stream) {
-    if (B == 0) return CHB_OK;
-    if (!in || !out || !ops_host || B < 0 || H <= 0 || W <= 0 || n_ops < 1 || n_ops > CHB_FUSED_MAX_OPS || patch < 0 || (patch & 3)) return CHB_EINVAL;
-    if ((int64_t)H * W * 3 >= 2147483647LL || B > 65535) return CHB_EUNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
+static bool fused_is_local(int op) { return op != CHB_AUG_AFFINE && op != CHB_AUG_SHARPNESS; }
+
+// one segment of a chain: ops[0..n) evaluated per output pixel of `src`; returns the number of tables it used
+static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int n_ops, const FusedOp* ops, const int32_t* const* centers,
+                         int32_t* ws, int patch, hipStream_t s) {
     FusedParams P;
     memset(&P, 0, sizeof(P));
     P.n = n_ops; P.B = B; P.H = H; P.W = W;
-    memcpy(P.ops, ops_host, sizeof(FusedOp) * n_ops);
+    const int fast = ((W & 3) == 0 && !((uintptr_t)src & 3) && (patch || !((uintptr_t)dst & 3))) ? 1 : 0;
     int n_tables = 0;
+    bool local = true;
     for (int l = 0; l < n_ops; ++l) {
-        const int op = P.ops[l].op;
-        if (op < CHB_AUG_IDENTITY || op > CHB_AUG_CUTOUT) return CHB_EINVAL;
-        if (op == CHB_AUG_CUTOUT) {
-            if (!centers_dev || !centers_dev[l]) return CHB_EINVAL;
-            P.centers[l] = centers_dev[l];
-        }
-        if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
-            if (!workspace) return CHB_EINVAL;
-            P.lut[l] = workspace + (int64_t)n_tables * B * 768;
-            ++n_tables;
-        }
+        P.ops[l] = ops[l];
+        P.centers[l] = centers[l];
+        local = local && fused_is_local(ops[l].op);
+        if (ops[l].op == CHB_AUG_AUTOCONTRAST || ops[l].op == CHB_AUG_EQUALIZE) P.lut[l] = ws + (int64_t)(n_tables++) * B * 768;
     }
     // table ops, in chain order: histogram of the level below (evaluated through everything under it), then the table
     for (int l = 0; l < n_ops; ++l) {
         if (!P.lut[l]) continue;
-        int32_t* ws = const_cast<int32_t*>(P.lut[l]);
+        int32_t* t = const_cast<int32_t*>(P.lut[l]);
         const int nws = B * 768;
-        hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, ws, nws, 1);
-        const int sl = slices_for((int64_t)H * W * 12, B);
-        const dim3 grid(sl, B);
+        const int minmax = ops[l].op == CHB_AUG_AUTOCONTRAST ? 1 : 0;
+        hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, t, nws, minmax ? 0 : 1);
+        const dim3 grid(slices_for((int64_t)H * W * 3, B), B);
+#define CHB_FUSED_HIST(NL)                                                                                              \
+    do {                                                                                                                \
+        if (local) hipLaunchKernelGGL((fused_hist_kernel<NL, true>), grid, dim3(256), 0, s, src, t, P, fast, minmax);     \
+        else hipLaunchKernelGGL((fused_hist_kernel<NL, false>), grid, dim3(256), 0, s, src, t, P, fast, minmax);          \
+    } while (0)
         switch (l) {
-            case 0: hipLaunchKernelGGL(fused_hist_kernel<0>, grid, dim3(256), 0, s, in, ws, P); break;
-            case 1: hipLaunchKernelGGL(fused_hist_kernel<1>, grid, dim3(256), 0, s, in, ws, P); break;
-            case 2: hipLaunchKernelGGL(fused_hist_kernel<2>, grid, dim3(256), 0, s, in, ws, P); break;
-            default: hipLaunchKernelGGL(fused_hist_kernel<3>, grid, dim3(256), 0, s, in, ws, P); break;
+            case 0: CHB_FUSED_HIST(0); break;
+            case 1: CHB_FUSED_HIST(1); break;
+            case 2: CHB_FUSED_HIST(2); break;
+            default: CHB_FUSED_HIST(3); break;
         }
-        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, ws, P.ops[l].op);
+#undef CHB_FUSED_HIST
+        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, ops[l].op);
     }
     int gh = 0, gw = 0;
-    int64_t total;
-    if (patch) {
-        gh = H / patch; gw = W / patch;
-        if (gh == 0 || gw == 0) return CHB_EINVAL;
-        total = (int64_t)B * gh * patch * ((gw * patch) / 4);
-    } else {
-        total = (int64_t)B * H * ((W + 3) / 4);
-    }
-    const int grid = stream_grid(total);
-#define CHB_FUSED_FINAL(NL)                                                                                                   \
-    do {                                                                                                                      \
-        if (patch) hipLaunchKernelGGL((fused_final_kernel<NL, true>), dim3(grid), dim3(256), 0, s, in, out, P, patch, gh, gw);  \
-        else hipLaunchKernelGGL((fused_final_kernel<NL, false>), dim3(grid), dim3(256), 0, s, in, out, P, patch, gh, gw);       \
+    if (patch) { gh = H / patch; gw = W / patch; }
+    const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);
+#define CHB_FUSED_FINAL2(NL, PT)                                                                                                   \
+    do {                                                                                                                           \
+        if (local) hipLaunchKernelGGL((fused_final_kernel<NL, PT, true>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);  \
+        else hipLaunchKernelGGL((fused_final_kernel<NL, PT, false>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);       \
+    } while (0)
+#define CHB_FUSED_FINAL(NL)                \
+    do {                                   \
+        if (patch) CHB_FUSED_FINAL2(NL, true); \
+        else CHB_FUSED_FINAL2(NL, false);      \
     } while (0)
     switch (n_ops) {
         case 1: CHB_FUSED_FINAL(1); break;
@@ -1574,6 +1740,66 @@ int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, 
         default: CHB_FUSED_FINAL(4); break;
     }
 #undef CHB_FUSED_FINAL
+#undef CHB_FUSED_FINAL2
+    return n_tables;
+}
+
+int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* ops_host, const int32_t* const* centers_dev,
+                  int32_t* workspace, uint8_t* scratch, int patch, void* stream) {
+    if (B == 0) return CHB_OK;
+    if (!in || !out || !ops_host || B < 0 || H <= 0 || W <= 0 || n_ops < 1 || n_ops > CHB_FUSED_MAX_OPS || patch < 0 || (patch & 3)) return CHB_EINVAL;
+    if ((int64_t)H * W * 3 >= 2147483647LL - 4 || B > 65535) return CHB_EUNSUPPORTED;
+    if (patch && (H / patch == 0 || W / patch == 0)) return CHB_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    FusedOp ops[CHB_FUSED_MAX_OPS];
+    const int32_t* centers[CHB_FUSED_MAX_OPS];
+    memcpy(ops, ops_host, sizeof(FusedOp) * n_ops);
+    for (int l = 0; l < n_ops; ++l) {
+        const int op = ops[l].op;
+        if (op < CHB_AUG_IDENTITY || op > CHB_AUG_CUTOUT) return CHB_EINVAL;
+        centers[l] = (op == CHB_AUG_CUTOUT && centers_dev) ? centers_dev[l] : nullptr;
+        if (op == CHB_AUG_CUTOUT && !centers[l]) return CHB_EINVAL;
+        if ((op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) && !workspace) return CHB_EINVAL;
+    }
+    if (!scratch) {    // no memory for an intermediate image: the whole chain per output pixel, gathers and all
+        fused_segment(in, out, B, H, W, n_ops, ops, centers, workspace, patch, s);
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
+    // With scratch the chain is cut at its Sharpness ops: a Sharpness reads a MATERIALISED image through its own kernel (rows
+    // shared between outputs) - evaluating the levels under it at nine taps, or it under a warp's gather, costs more than the
+    // uint8 round trip (profiles/r02_augment_stage.txt).  Everything between two cuts is one launch: per output pixel one gather
+    // at most (a warp), the pixel-local ops around it applied to that pixel; without a warp, the register-lean LOCAL kernel.
+    // The last segment writes `out`, with the normalisation and the patch gather folded in.
+    const int64_t img_bytes = (int64_t)B * H * W * 3;
+    const uint8_t* src = in;
+    int lo = 0, n_cut = 0;
+    int32_t* ws = workspace;
+    while (lo < n_ops) {
+        const bool sharp = ops[lo].op == CHB_AUG_SHARPNESS;
+        int hi = lo + 1;
+        if (!sharp)
+            while (hi < n_ops && ops[hi].op != CHB_AUG_SHARPNESS) ++hi;
+        const bool last = hi == n_ops;
+        void* dst = (last && !(sharp && patch)) ? out : (void*)(scratch + (int64_t)(n_cut & 1) * img_bytes);
+        if (sharp) {
+            const int rc = chb_aug_sharpness(src, (uint8_t*)dst, B, H, W, 3, ops[lo].f[0], stream);
+            if (rc != CHB_OK) return rc;
+            if (last && patch) {      // the patch rows of the sharpened image
+                FusedOp ident;
+                memset(&ident, 0, sizeof(ident));
+                ident.op = CHB_AUG_IDENTITY;
+                const int32_t* none = nullptr;
+                fused_segment((const uint8_t*)dst, out, B, H, W, 1, &ident, &none, nullptr, patch, s);
+            }
+        } else {
+            const int nt = fused_segment(src, dst, B, H, W, hi - lo, ops + lo, centers + lo, ws, last ? patch : 0, s);
+            if (ws) ws += (int64_t)nt * B * 768;
+        }
+        src = (const uint8_t*)dst;
+        ++n_cut;
+        lo = hi;
+    }
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

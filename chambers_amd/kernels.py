@@ -152,9 +152,10 @@ class AugPlan:
         return sum(int(it["op"]) in (_lib.AUG_AUTOCONTRAST, _lib.AUG_EQUALIZE) for it in self.items)
 
 
-def aug_fused(x, plan, patch=None, out=None):
+def aug_fused(x, plan, patch=None, out=None, scratch=True):
     """One launch for a whole batch-shared op chain (plus one histogram pass per AutoContrast / Equalize in it).
-    patch=None: uint8 NHWC result;  patch=P: bf16 patch rows of the "tf"-normalised result (normalize_patchify fused in)."""
+    patch=None: uint8 NHWC result;  patch=P: bf16 patch rows of the "tf"-normalised result (normalize_patchify fused in).
+    scratch=True lets a chain be cut at its Sharpness ops (chb_aug_fused's scratch argument)."""
     x = _u8_nhwc(x)
     b, h, w, c = x.shape
     if c != 3:
@@ -170,10 +171,17 @@ def aug_fused(x, plan, patch=None, out=None):
         recs[l]["i"] = it["i"]
         recs[l]["f"] = it["f"][:6]
         if int(it["op"]) == _lib.AUG_CUTOUT:
-            cen = np.ascontiguousarray(plan.centers[l], dtype=np.int32)
-            if cen.shape != (b, 2):
-                raise ValueError("CutOut wants one (cy, cx) per image: expected %s, got %s" % ((b, 2), cen.shape))
-            dev = _upload(cen, x.device)
+            cen = plan.centers[l]
+            if isinstance(cen, torch.Tensor):        # resident decisions
+                _lib.require_gpu(cen)
+                dev = cen.to(torch.int32).contiguous()
+            else:
+                cen = np.ascontiguousarray(cen, dtype=np.int32)
+                dev = None
+            if tuple(cen.shape) != (b, 2):
+                raise ValueError("CutOut wants one (cy, cx) per image: expected %s, got %s" % ((b, 2), tuple(cen.shape)))
+            if dev is None:
+                dev = _upload(cen, x.device)
             keep.append(dev)
             cptr[l] = dev.data_ptr()
     nt = plan.n_tables
@@ -188,8 +196,11 @@ def aug_fused(x, plan, patch=None, out=None):
             out = torch.empty((rows, patch * patch * 3), dtype=torch.bfloat16, device=x.device)
         if out.dtype != torch.bfloat16 or out.numel() < rows * patch * patch * 3 or not out.is_contiguous():
             raise ValueError("out must be a contiguous bf16 buffer of at least %d patch rows" % rows)
+    ops = [int(it["op"]) for it in plan.items]
+    cut = _lib.AUG_SHARPNESS in ops and (n > 1 or patch is not None)
+    scratch = torch.empty((2,) + tuple(x.shape), dtype=torch.uint8, device=x.device) if (cut and scratch) else None
     _lib.call("chb_aug_fused", _lib.ptr(x), _lib.ptr(out), b, h, w, n, recs.ctypes.data, ctypes.cast(cptr, ctypes.c_void_p),
-              _lib.ptr(ws), 0 if patch is None else int(patch), _s())
+              _lib.ptr(ws), _lib.ptr(scratch), 0 if patch is None else int(patch), _s())
     return out
 
 

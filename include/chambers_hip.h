@@ -296,12 +296,15 @@ int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const
  *   Contrast's i0 is the constant of the whole batch tensor, B*H*W/256 clipped), applied in order.
  * centers_dev[l]: device int32 [B,2] (cy, cx) for a CutOut at level l (else ignored / NULL).  workspace: int32 [n_tables*B*768]
  * when the chain holds AutoContrast / Equalize (each costs a histogram pass of the level below it + a table launch).
+ * scratch: NULL, or 2*B*H*W*3 bytes.  NULL: the whole chain is evaluated per output pixel, the levels under a Sharpness at
+ * each of its nine taps.  With scratch the chain is cut at its Sharpness ops, which then read a materialised uint8 image
+ * through the stand-alone kernel (same bytes out, fewer gathers; the faster route); everything between two cuts is one launch.
  * patch == 0: out = uint8 NHWC [B,H,W,3] (the chain's image);  patch > 0 (multiple of 4): out = bf16 [B*(H/patch)*(W/patch),
  * patch*patch*3] patch rows of the "tf"-normalised chain output (what chb_normalize_patchify_bf16 would produce from it).
  * Bit-identical to running the ops one after the other. */
 #define CHB_FUSED_MAX_OPS 4
 int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* ops_host,
-                  const int32_t* const* centers_dev, int32_t* workspace, int patch, void* stream);
+                  const int32_t* const* centers_dev, int32_t* workspace, uint8_t* scratch, int patch, void* stream);
 
 /* Tuning / A-B switch `name` (ATTN_FWD_ALGO, ATTN_BWD_ALGO, AFFINE_ALGO, GEMM_ALGO, GEMM_WALK, TN_ATOMICS, TN_FAST,
  * GEMM_EPI_OVERLAP; csrc/common.hpp) := value.  Defaults come from the environment variables CHB_<name>, read once per
