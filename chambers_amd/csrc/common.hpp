@@ -112,11 +112,11 @@ enum ChbOption {
     CHB_OPT_ATTN_FWD_ALGO = 0,   // 0 auto (whole-head kernel for N <= 224), 1 resident (N <= 224), 2 streaming
     CHB_OPT_ATTN_BWD_ALGO,       // 0 auto (lean one-pass kernel unless the fused bias gradient is asked for), 1 resident 8 waves, 2 two-pass, 3 resident 16 waves, 4 = 0 without a bias gradient
     CHB_OPT_AFFINE_ALGO,         // 0 auto, 1 rows, 2 32x8 tiles, 3 16x16 tiles
-    CHB_OPT_GEMM_ALGO,           // 0 auto, 1 128x128 tiles, 2 persistent 256x256, 3 persistent 128x256 x 2 workgroups / CU
+    CHB_OPT_GEMM_ALGO,           // 0 auto, 1 128x128 tiles, 2 persistent 256x256, 3 persistent 128x256 x 2 workgroups / CU, 4 persistent 256x256 ping-pong (full tiles)
     CHB_OPT_GEMM_WALK,           // 0 linear tile ids per XCD, 1 (default) panel walk where it pays, 2 always panel
     CHB_OPT_TN_ATOMICS,          // 1 = always the atomic epilogue
     CHB_OPT_TN_FAST,             // 0 = generic staging addresses everywhere (default 1)
-    CHB_OPT_GEMM_EPI_OVERLAP,    // 1 (default) = epilogue of tile i inside the K-loop of tile i+1, 0 = epilogue after the last K-tile
+    CHB_OPT_GEMM_TILE_QUEUE,     // 1 (default) = persistent NT GEMM workgroups claim their tiles after the first from per-XCD counters, 0 = static tile shares
     CHB_OPT_DEBUG,               // timing experiments only (tools/): e.g. 1 = attention backward without its main loop; results are WRONG
     CHB_OPT_COUNT
 };

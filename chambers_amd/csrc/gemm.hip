@@ -16,10 +16,18 @@
 #include "common.hpp"
 #include "../../include/chambers_hip.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+// tile rows of epilogue inputs (residual / saved gelu') requested ahead of the row being written; -D overrides are for A/B builds
+#ifndef EPI_DEPTH_RESID
+#define EPI_DEPTH_RESID 1
+#endif
+#ifndef EPI_DEPTH_DGELU
+#define EPI_DEPTH_DGELU 1
+#endif
 constexpr int TILE_ELEMS = 128 * 64;  // one operand tile, either orientation
 
 struct GemmParams {
@@ -36,6 +44,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     float* colsum;   // optional fp32 [N]: += column sums of the output (bias gradient of the consumer layer)
     int walk_panel;  // persistent 256x256 kernel: XCD-panel tile walk (see TileWalk)
+    int queue_slot;  // persistent 256x256 kernel: >= 0 = tiles after a workgroup's first are claimed from per-XCD counters of this slot
 };
 
 // bijective XCD-aware remap: consecutive virtual ids (which share an A panel) stay on one XCD
@@ -252,11 +261,37 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
     const float* rd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) rd[k] = stage + (4 * k + cr) * 64 + ((c4 ^ (4 * k + cr)) << 2);
+    // The epilogue's own global loads (residual / saved gelu' / positional rows) run DEPTH tile rows ahead: the loads of row
+    // a + DEPTH are issued before row a crosses LDS.  Measured (tools/ab_build.sh, depths 0-5 A/B in one session): no depth
+    // changes the wall time of any shape by more than run-to-run noise (+-2 %) - the epilogue is not waiting on these loads.
+    constexpr bool HAS_IN = (EPI == CHB_EPI_PATCH || EPI == CHB_EPI_RESID || EPI == CHB_EPI_DGELU);
+    constexpr int DEPTH = (EPI == CHB_EPI_RESID) ? EPI_DEPTH_RESID : (EPI == CHB_EPI_DGELU) ? EPI_DEPTH_DGELU : 1;   // rows in flight ahead
+    float4 r4buf[DEPTH + 1][4];
+    uint2 a2buf[DEPTH + 1][4];
+    auto load_inputs = [&](int a, float4 (&r4)[4], uint2 (&a2)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rr = a * 16 + 4 * k;
+            const int row = m_base + rr + cr;
+            const bool okk = colok && (!GUARD || row < p.M);
+            if (EPI == CHB_EPI_PATCH) {
+                const int bi = row / p.period, pp = row - bi * p.period;
+                if (okk) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.n_special + pp) * p.ld_resid + col);
+            }
+            if (EPI == CHB_EPI_RESID && okk) r4[k] = *reinterpret_cast<const float4*>(rbase + rr * rstep);
+            if (EPI == CHB_EPI_DGELU && okk) a2[k] = *reinterpret_cast<const uint2*>(abase + rr * astep);
+        }
+    };
+    if (HAS_IN) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (A0 + d < A1) load_inputs(A0 + d, r4buf[d % (DEPTH + 1)], a2buf[d % (DEPTH + 1)]);
+    }
 #pragma unroll
     for (int a = A0; a < A1; ++a) {
-        // inputs of this tile row first (they fly while the accumulators cross LDS)
-        float4 r4[4];
-        uint2 a2[4];
+        float4 (&r4)[4] = r4buf[(a - A0) % (DEPTH + 1)];
+        uint2 (&a2)[4] = a2buf[(a - A0) % (DEPTH + 1)];
+        if (HAS_IN && a + DEPTH < A1) load_inputs(a + DEPTH, r4buf[(a + DEPTH - A0) % (DEPTH + 1)], a2buf[(a + DEPTH - A0) % (DEPTH + 1)]);
         int64_t orow[4];
         bool ok[4];
 #pragma unroll
@@ -268,10 +303,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
             if (EPI == CHB_EPI_PATCH) {
                 const int bi = row / p.period, pp = row - bi * p.period;
                 orow[k] = (int64_t)bi * (p.period + p.n_special) + p.n_special + pp;
-                if (ok[k]) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.n_special + pp) * p.ld_resid + col);
             }
-            if (EPI == CHB_EPI_RESID && ok[k]) r4[k] = *reinterpret_cast<const float4*>(rbase + rr * rstep);
-            if (EPI == CHB_EPI_DGELU && ok[k]) a2[k] = *reinterpret_cast<const uint2*>(abase + rr * astep);
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) *reinterpret_cast<float4_t*>(wr[b]) = acc[a][b];
@@ -343,7 +375,16 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
     }
 }
 
+// Tile queue of the persistent NT kernel: per launch slot, one counter per XCD (the XCD's tile list is private to its workgroups)
+// and one hand-off word per workgroup (wave 0 claims, the other waves read the claim two barriers later).  Zero at load time; the
+// workgroup that draws an XCD's LAST ticket zeroes its counter again, so a slot is clean whenever its launch has ended.
+constexpr int TILE_QUEUE_SLOTS = 64;
+__device__ int g_tile_ctr[TILE_QUEUE_SLOTS][8];
+__device__ int g_tile_claim[TILE_QUEUE_SLOTS][512];
+
 struct TileWalk {
+    int dyn;                        // tile queue on: tile j > 0 of this workgroup is li_tab[j & 3] (claimed), not slot + j*stride
+    int li_tab[4];
     int start, cnt, slot, stride;   // this workgroup's tiles: start + slot + j*stride, j = 0.. while < cnt
     int tiles_n, ntk;
     // panel walk (bn > 0): the XCD owns m-tiles [mlo, mlo + mcnt) and sweeps them one bn-wide column of n-tiles at a time,
@@ -359,7 +400,11 @@ struct Cursor {   // (output tile, k-tile) position of a staging stream
 __device__ __forceinline__ void cursor_set(Cursor& c, const TileWalk& w, int j) {
     c.j = j;
     c.kt = 0;
-    const int li = w.slot + j * w.stride;
+    int li = w.slot + j * w.stride;
+    if (w.dyn) {
+        const int q = j & 3;
+        li = q == 0 ? w.li_tab[0] : q == 1 ? w.li_tab[1] : q == 2 ? w.li_tab[2] : w.li_tab[3];
+    }
     c.valid = li < w.cnt;
     if (w.bn > 0) {
         const int l = c.valid ? li : 0;
@@ -414,6 +459,33 @@ __device__ __forceinline__ void stage_half_any(const bf16_t* __restrict__ g, int
     else stage_half(g, ld, row0, max_row, k0, lds_half, wave, lane);
 }
 
+__device__ __forceinline__ void tile_walk_init(TileWalk& w, const GemmParams& p) {
+    const int nb = p.tiles_m * p.tiles_n;
+    const int q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
+    w.start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    w.cnt = q + (x < r ? 1 : 0);
+    w.slot = blockIdx.x >> 3;
+    w.stride = gridDim.x >> 3;
+    w.tiles_n = p.tiles_n;
+    w.ntk = p.K / BK;
+    w.bn = 0; w.mlo = 0; w.mcnt = 0;
+    w.dyn = 0;
+    w.li_tab[0] = w.slot; w.li_tab[1] = w.li_tab[2] = w.li_tab[3] = 0x7fffffff;
+    const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
+    // (32 / bn + bn) tiles of A + B per round is smallest near bn = sqrt(32); the panel walk is taken when the m-tiles split
+    // over the XCDs with <= 1/16 imbalance and the footprint shrinks by a quarter or more (N = 3072 here: L2-side fetch
+    // 1.7 GB -> 1.1 GB per launch, profiles/); narrower outputs keep the linear walk, which measured a few % faster there
+    const int ncols = max(1, (int)((float)p.tiles_n / 5.66f + 0.5f));
+    const int bn = (p.tiles_n + ncols - 1) / ncols;
+    const bool pays = 4.0f * (32.0f / p.tiles_n + p.tiles_n) >= 5.0f * (32.0f / bn + bn);
+    if (qm >= 16 && (p.walk_panel == 2 || (p.walk_panel == 1 && pays))) {
+        w.mlo = x * qm + min(x, rm);
+        w.mcnt = qm + (x < rm ? 1 : 0);
+        w.cnt = w.mcnt * p.tiles_n;
+        w.bn = bn;
+    }
+}
+
 template <int EPI, int OUT, bool FAST = false>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     // 128 KiB operand ring [2][A0 A1 B0 B1][128 x 64] + 8 x 4 KiB wave-private epilogue scratch = the CU's whole 160 KiB
@@ -425,33 +497,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     const int g = lane >> 4, i = lane & 15;
 
     TileWalk w;
-    {
-        const int nb = p.tiles_m * p.tiles_n;
-        const int q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
-        w.start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-        w.cnt = q + (x < r ? 1 : 0);
-        w.slot = blockIdx.x >> 3;
-        w.stride = gridDim.x >> 3;
-        w.tiles_n = p.tiles_n;
-        w.ntk = p.K / BK;
-        w.bn = 0; w.mlo = 0; w.mcnt = 0;
-        const int qm = p.tiles_m >> 3, rm = p.tiles_m & 7;
-        // (32 / bn + bn) tiles of A + B per round is smallest near bn = sqrt(32); the panel walk is taken when the m-tiles split
-        // over the XCDs with <= 1/16 imbalance and the footprint shrinks by a quarter or more (N = 3072 here: L2-side fetch
-        // 1.7 GB -> 1.1 GB per launch, profiles/); narrower outputs keep the linear walk, which measured a few % faster there
-        const int ncols = max(1, (int)((float)p.tiles_n / 5.66f + 0.5f));
-        const int bn = (p.tiles_n + ncols - 1) / ncols;
-        const bool pays = 4.0f * (32.0f / p.tiles_n + p.tiles_n) >= 5.0f * (32.0f / bn + bn);
-        if (qm >= 16 && (p.walk_panel == 2 || (p.walk_panel == 1 && pays))) {
-            w.mlo = x * qm + min(x, rm);
-            w.mcnt = qm + (x < rm ? 1 : 0);
-            w.cnt = w.mcnt * p.tiles_n;
-            w.bn = bn;
-        }
-    }
+    tile_walk_init(w, p);
     if (w.slot >= w.cnt) return;
-    const int nmy = (w.cnt - w.slot + w.stride - 1) / w.stride;
-    const int total = nmy * w.ntk;
+    // Tile queue (K >= 8 K-tiles): a workgroup's first tile is its static one, every later tile is the next ticket of its XCD's
+    // counter.  A workgroup that starts late (its CU was held by another stream's kernel - a collective) then simply draws fewer
+    // tickets: the launch loses that CU's share of the time it was away, not a whole static tile share at the end.
+    // Tile j + 1 is claimed while tile j is young: wave 0 draws the ticket at the end of K-step 0, hands it over through
+    // g_tile_claim in K-step 2 (the atomic has returned by K-step 1's vmcnt(0)), every wave picks it up in K-step 4 (wave 0's
+    // store is two barriers old) - the staging streams need it from K-step ntk - 2 on.
+    w.dyn = (p.queue_slot >= 0 && w.ntk >= 8) ? 1 : 0;
+    int* q_ctr = &g_tile_ctr[w.dyn ? p.queue_slot : 0][blockIdx.x & 7];
+    int* q_claim = &g_tile_claim[w.dyn ? p.queue_slot : 0][blockIdx.x & 511];
+    int q_ticket = 0, q_seen = 0;
 
     // lane-constant byte offsets of the two LDS-DMA instructions a wave issues per half-tile (row 64 j + 8 wave + lane / 8)
     uint32_t offa[2], offb[2];
@@ -497,9 +554,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     const int a_off0 = i * 64 + (((0 + g) ^ sw) << 3), a_off1 = i * 64 + (((4 + g) ^ sw) << 3);
     const int b_off0 = ((wn & 1) * 64 + i) * 64 + (((0 + g) ^ sw) << 3), b_off1 = ((wn & 1) * 64 + i) * 64 + (((4 + g) ^ sw) << 3);
 
-    for (int s = 0; s < total; ++s) {
+    for (int s = 0; cc.valid; ++s) {
         bf16_t* ring = smem + (s & 1) * 4 * 8192;
         bf16_t* nring = smem + ((s + 1) & 1) * 4 * 8192;
+        if (w.dyn && cc.kt == 4) q_seen = __hip_atomic_load(q_claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // wave-uniform branch
         const bf16_t* As = ring + wm * 8192;
         const bf16_t* Bs = ring + (2 + (wn >> 1)) * 8192;
         bf16x8_t af[4][2], bq[4][2];
@@ -544,6 +602,32 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A and B half-tiles; step s+1 has landed
         __builtin_amdgcn_sched_barrier(0);
+        if (w.dyn) {
+            // the ticket is drawn right behind this step's vmcnt(0), so its round trip (up to ~3 k cycles when every CU draws at
+            // once) has two whole K-steps before a wait covers it - drawn at the top of the step it stalled that step's wait
+            // (inline asm: hipcc's atomicAdd aggregates over the wave and reads the result back at once - an s_waitcnt vmcnt(0)
+            // right behind the atomic, which stalled wave 0 and with it the workgroup for the whole round trip; an asm result is
+            // outside its bookkeeping, the K-loop's own vmcnt(0) of the next step covers it.  Lane 0 only, in-place operand.)
+            if (cc.kt == 0 && wave == 0) {      // scalar branch
+                q_ticket = 1;
+                uint64_t save;
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %[t], %[off], %[t], %[ptr] sc0\n\ts_mov_b64 exec, %[sv]"
+                             : [t] "+v"(q_ticket), [sv] "=&s"(save)
+                             : [off] "v"(0), [ptr] "s"(q_ctr)
+                             : "memory");
+            }
+            if (cc.kt == 2 && wave == 0 && lane == 0) {
+                // tickets 0 .. cnt-1 are drawn per XCD and launch (one per tile started): ticket t is tile stride + t of the
+                // XCD's list, and whoever holds the last one leaves the counter clean for the slot's next launch
+                __hip_atomic_store(q_claim, w.stride + q_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q_ticket == w.cnt - 1) __hip_atomic_store(q_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (cc.kt == 4) {
+                const int nxt = __builtin_amdgcn_readfirstlane(q_seen);
+                const int q = (cc.j + 1) & 3;
+                if (q == 0) w.li_tab[0] = nxt; else if (q == 1) w.li_tab[1] = nxt; else if (q == 2) w.li_tab[2] = nxt; else w.li_tab[3] = nxt;
+            }
+        }
         if (cb.valid) {                        // this ring's B slots are free now: step s+2 goes into them
             stage_half_any<FAST>(p.B, p.ldb, cb.n0, p.N, cb.kt * BK, offb, ring + 2 * 8192, wave, lane);
             stage_half_any<FAST>(p.B, p.ldb, cb.n0 + 128, p.N, cb.kt * BK, offb, ring + 3 * 8192, wave, lane);
@@ -572,6 +656,170 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         }
         cursor_next(cc, w);
     }
+}
+
+
+// ---- NT, persistent 256x256 tiles, two wave groups in anti-phase ("ping-pong") ----------------------------------------------
+// Same geometry as gemm_nt256_kernel (8 waves = 2(M) x 4(N), 128x64 outputs per wave, 64-deep K-tiles, 128 KiB ring + 32 KiB
+// epilogue scratch), different clock-work: a K-tile is FOUR phases of 16 MFMAs (one quadrant of the wave's outputs each), every
+// phase is  { ds_read this quadrant's fragments | issue one 16 KiB staging element | counted vmcnt | barrier | lgkmcnt(0) |
+// 16 MFMAs | barrier },  and the waves of group 1 (rows 128-255) run ONE BARRIER behind those of group 0.  A SIMD hosts one wave
+// of each group, so while one reads LDS and issues DMA the other owns the MFMA pipe, and they swap every barrier - the pipe no
+// longer waits for a CU-wide fragment-read burst (gemm_nt256_kernel: both waves of a SIMD leave its barrier together and want
+// the same unit).
+//
+// Staging elements are cut so that each is READ IN EXACTLY ONE PHASE (16 KiB = 128 rows x 64 k, two LDS-DMA instructions per wave):
+//   e0 = A rows {128 grp + r, r < 64}        (both groups' first row halves)    read in phase 0
+//   e1 = B rows {64 wn + r, r < 32}          (every wave's first 32 columns)    read in phase 0, fragments kept for phase 3
+//   e2 = B rows {64 wn + 32 + r}                                               read in phase 1, kept for phase 2
+//   e3 = A rows {128 grp + 64 + r}                                             read in phase 2
+// Stream element h = 4 T + e (T = K-tile counter across output tiles) lives in ring slot h & 7.  In phase c = 4 T + p a wave
+// issues element c + 6 and waits vmcnt(8): all but the four youngest elements have landed, i.e. everything up to c + 2, which is
+// what phase c + 1 reads (RAW: a read comes one phase after the wait that retires its element, with a barrier between; WAR:
+// element h overwrites h - 8, last read in phase h - 8 or h - 9, at least two phases - four barriers - earlier, so the lagging
+// group's reads have retired too).  Epilogue stores share the vmcnt counter: the epilogue ends with a wait that leaves only ITS
+// operations outstanding (so every element issued before it has landed) and the first K-tile of the next output tile, which
+// reads only those elements, waits for nothing.
+// Full tiles only (M % 256 == 0, N % 256 == 0) and K >= 4 K-tiles; launch_nt falls back to gemm_nt256_kernel otherwise.
+template <int EPI, int OUT>
+__global__ void __launch_bounds__(512, 2) gemm_nt256pp_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[8 * 8192 + 8 * 2048];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int grp = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, i = lane & 15;
+
+    TileWalk w;
+    tile_walk_init(w, p);
+    if (w.slot >= w.cnt) return;
+    const int nmy = (w.cnt - w.slot + w.stride - 1) / w.stride;
+    const int total = nmy * w.ntk;
+
+    // lane-constant byte offsets of the two LDS-DMA instructions of an element: element row r = 8 (8 j + wave) + lane / 8
+    uint32_t offa[2], offb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        offa[j] = (uint32_t)(((int64_t)((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2);
+        offb[j] = (uint32_t)(((int64_t)((r >> 5) * 64 + (r & 31)) * p.ldb + c * 8) * 2);
+    }
+    // The staging stream runs six elements ahead of the compute phase: phase p of K-tile T issues element p + 2 of the stream's
+    // K-tile (T + 1 for p = 0, 1; T + 2 for p = 2, 3), so which element a phase stages is a compile-time fact and the stream's
+    // two row pointers move once per K-tile (scalar work per phase: one add and the LDS slot).
+    Cursor cs, cc;
+    cursor_set(cs, w, 0);
+    cursor_set(cc, w, 0);
+    const char* sa = nullptr;     // stream K-tile: A rows m0.., B rows n0.. at its k offset
+    const char* sb = nullptr;
+    auto stream_ptrs = [&]() {
+        sa = reinterpret_cast<const char*>(p.A + (int64_t)cs.m0 * p.lda + cs.kt * BK);
+        sb = reinterpret_cast<const char*>(p.B + (int64_t)cs.n0 * p.ldb + cs.kt * BK);
+    };
+    const int64_t a_half = (int64_t)64 * p.lda * 2, b_half = (int64_t)32 * p.ldb * 2;      // bytes to e3 / e2 from e0 / e1
+    // element E (compile time) of the stream's K-tile into ring slot `slot`
+#define CHB_PP_STAGE(E, slot)                                                                                     \
+    {                                                                                                             \
+        bf16_t* dst_ = smem + (slot) * 8192;                                                                       \
+        if ((E) == 0) stage_half_fast(sa, offa, dst_, wave);                                                      \
+        else if ((E) == 3) stage_half_fast(sa + a_half, offa, dst_, wave);                                        \
+        else if ((E) == 1) stage_half_fast(sb, offb, dst_, wave);                                                 \
+        else stage_half_fast(sb + b_half, offb, dst_, wave);                                                      \
+    }
+    stream_ptrs();
+    CHB_PP_STAGE(0, 0) CHB_PP_STAGE(1, 1) CHB_PP_STAGE(2, 2) CHB_PP_STAGE(3, 3)
+    cursor_next(cs, w);          // K >= 4 K-tiles: the stream's second K-tile exists
+    stream_ptrs();
+    CHB_PP_STAGE(0, 4) CHB_PP_STAGE(1, 5)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind from here on
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int sw = (i >> 1) & 7;
+    const int a_off0 = (grp * 64 + i) * 64 + (((0 + g) ^ sw) << 3), a_off1 = (grp * 64 + i) * 64 + (((4 + g) ^ sw) << 3);
+    const int b_off0 = (wn * 32 + i) * 64 + (((0 + g) ^ sw) << 3), b_off1 = (wn * 32 + i) * 64 + (((4 + g) ^ sw) << 3);
+    float* stage = reinterpret_cast<float*>(smem + 8 * 8192) + wave * 1024;
+    bf16x8_t af[4][2], bq[4][2];
+
+#define CHB_PP_SYNC_MFMA(A0, B0, E, SLOT)                                                                                            \
+    {                                                                                                                             \
+        const bool staged = cs.valid;                                                                                             \
+        if (staged) CHB_PP_STAGE(E, SLOT)                                                                                         \
+        if (!first_kt) {                                                                                                          \
+            if (staged) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                          \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        }                                                                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                          \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                         \
+                _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                     \
+                    acc[A0 + a][B0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[B0 + b][ks], af[a][ks], acc[A0 + a][B0 + b], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                                             \
+    }
+
+    for (int T = 0; T < total; ++T) {
+        const bf16_t* ring = smem + (T & 1) * 4 * 8192;
+        const bool first_kt = cc.kt == 0;
+        const bool last_k = cc.kt == w.ntk - 1;
+        // ---- phase 0: rows 0-63 x columns 0-31
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bq[b][ks] = *reinterpret_cast<const bf16x8_t*>(ring + 1 * 8192 + (ks ? b_off1 : b_off0) + b * 16 * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[a][ks] = *reinterpret_cast<const bf16x8_t*>(ring + 0 * 8192 + (ks ? a_off1 : a_off0) + a * 16 * 64);
+        CHB_PP_SYNC_MFMA(0, 0, 2, ((T + 1) & 1) * 4 + 2)
+        // ---- phase 1: rows 0-63 x columns 32-63
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bq[2 + b][ks] = *reinterpret_cast<const bf16x8_t*>(ring + 2 * 8192 + (ks ? b_off1 : b_off0) + b * 16 * 64);
+        CHB_PP_SYNC_MFMA(0, 2, 3, ((T + 1) & 1) * 4 + 3)
+        // the stream moves on to its next K-tile (elements 0 and 1 of it go out in phases 2 and 3)
+        if (cs.valid) {
+            cursor_next(cs, w);
+            if (cs.valid) stream_ptrs();
+        }
+        // ---- phase 2: rows 64-127 x columns 32-63
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[a][ks] = *reinterpret_cast<const bf16x8_t*>(ring + 3 * 8192 + (ks ? a_off1 : a_off0) + a * 16 * 64);
+        CHB_PP_SYNC_MFMA(4, 2, 0, (T & 1) * 4 + 0)
+        // ---- phase 3: rows 64-127 x columns 0-31 (fragments already in registers)
+        CHB_PP_SYNC_MFMA(4, 0, 1, (T & 1) * 4 + 1)
+
+        if (last_k) {
+            epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + grp * 128, cc.n0 + wn * 64, acc, lane);
+            // leave only (at most) the epilogue's own memory operations outstanding: every staging element issued before it has landed
+            constexpr int EPI_OPS = (EPI == CHB_EPI_NONE) ? 32 : 63;
+            if (EPI_OPS == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        cursor_next(cc, w);
+    }
+#undef CHB_PP_SYNC_MFMA
+#undef CHB_PP_STAGE
+    if (grp == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's extra barrier
 }
 
 // ---- TN (wgrad): operand tiles are [64 m rows][128 cols] (256-byte rows, 16 chunks) ----------
@@ -856,6 +1104,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt128_kernel(GemmParams p) {
         w.stride = gridDim.x >> 3;
         w.tiles_n = p.tiles_n;
         w.ntk = p.K / 32;
+        w.dyn = 0;
     }
     if (w.slot >= w.cnt) return;
     const int nmy = (w.cnt - w.slot + w.stride - 1) / w.stride;
@@ -1251,7 +1500,7 @@ template <int EPI>
 int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
     int algo = gemm_algo_override();
     if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? 2 : 1;
-    if (p.colsum && algo != 2) {
+    if (p.colsum && algo != 2 && algo != 4) {
         // only the persistent 256x256 kernel fuses the column sums; other paths add them with the stand-alone pass
         if (out_dtype != CHB_OUT_BF16) return CHB_EUNSUPPORTED;
         float* cs = p.colsum;
@@ -1268,6 +1517,19 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
         const dim3 g(grid), block(256);
         if (out_dtype == CHB_OUT_F32) hipLaunchKernelGGL((gemm_nt128_kernel<EPI, CHB_OUT_F32>), g, block, 0, s, p);
         else hipLaunchKernelGGL((gemm_nt128_kernel<EPI, CHB_OUT_BF16>), g, block, 0, s, p);
+        return CHB_OK;
+    }
+    if (algo == 4) {     // ping-pong schedule: full tiles and >= 4 K-tiles only
+        if ((p.M & 255) || (p.N & 255) || p.K < 4 * BK) algo = 2;
+    }
+    if (algo == 4) {
+        p.tiles_m = p.M / 256;
+        p.tiles_n = p.N / 256;
+        int grid = num_cus() & ~7;
+        if (grid < 8) grid = 8;
+        const dim3 g(grid), block(512);
+        if (out_dtype == CHB_OUT_F32) hipLaunchKernelGGL((gemm_nt256pp_kernel<EPI, CHB_OUT_F32>), g, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt256pp_kernel<EPI, CHB_OUT_BF16>), g, block, 0, s, p);
         return CHB_OK;
     }
     if (algo == 2) {
@@ -1321,6 +1583,10 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
     p.tiles_m = chb_div_up(M, BM); p.tiles_n = chb_div_up(N, BN);
     p.colsum = out_colsum;
     p.walk_panel = chb_option(CHB_OPT_GEMM_WALK);   // 0 = linear tile ids per XCD, 1 (default) = panel walk where it pays, 2 = always panel
+    {   // tile queue of the persistent kernel: a fresh slot per launch (launches in flight at once never share one)
+        static std::atomic<unsigned> launch_seq{0};
+        p.queue_slot = chb_option(CHB_OPT_GEMM_TILE_QUEUE) ? (int)(launch_seq.fetch_add(1, std::memory_order_relaxed) % TILE_QUEUE_SLOTS) : -1;
+    }
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         int rc;

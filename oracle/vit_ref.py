@@ -138,12 +138,17 @@ class _AttentionBf16(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+NATIVE_DROPOUT = "native"      # pass as every site's key: dropout masks from torch.rand (bench.py's cpu_baseline leg)
+
+
 def _drop(x, rate, key):
     """tf.nn.dropout: x * 1/(1-rate) * keep (keras Dropout, training)."""
     if rate == 0.0 or key is None:
         return x
-    keep = rng_ref.keep_mask(x.numel(), key, rate).reshape(tuple(x.shape))
     scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+    if isinstance(key, str):      # NATIVE_DROPOUT: masks from torch's generator (timing runs; no parity with the HIP path's masks)
+        return x * float(scale) * (torch.rand_like(x) >= rate).to(x.dtype)
+    keep = rng_ref.keep_mask(x.numel(), key, rate).reshape(tuple(x.shape))
     return x * float(scale) * torch.from_numpy(keep).to(x.dtype)
 
 
@@ -195,8 +200,8 @@ def multi_head_attention(x, p, prefix, num_heads, rate, key, bf16, taps=None):
     scores = torch.matmul(query, keyt.transpose(-1, -2)) / math.sqrt(head_dim)
     weights = torch.softmax(scores, dim=-1)
     if rate != 0.0 and key is not None:     # keras Attention dropout on the probabilities; mask index: rng_ref.attn_keep_mask
-        keep = rng_ref.attn_keep_mask(tuple(weights.shape), key, rate)
-        weights = weights * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * torch.from_numpy(keep).to(weights.dtype)
+        keep = (torch.rand_like(weights) >= rate) if isinstance(key, str) else torch.from_numpy(rng_ref.attn_keep_mask(tuple(weights.shape), key, rate))
+        weights = weights * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate))) * keep.to(weights.dtype)
     attn = torch.matmul(weights, value)
     if taps is not None:
         if attn.requires_grad:

@@ -194,6 +194,45 @@ def test_persistent_gemm_gelu_and_dgelu_colsum(m, n, k, out_f32):
     assert bool((out2[m:].float() == 9.0).all())
 
 
+@pytest.mark.parametrize("m,n,k,epi", [(8192, 1024, 768, "resid"), (8192 + 100, 1280, 512, "none"), (16384, 768, 1024, "gelu"),
+                                         (4096, 512, 448, "none")])
+def test_persistent_gemm_schedules_agree_bit_for_bit(m, n, k, epi):
+    """The same K order and accumulation order in every schedule of the persistent NT kernel: static tile shares vs the per-XCD
+    tile queue (K >= 8 K-tiles; 70 launches so that every queue slot is used twice and must have been left clean), and the
+    lockstep vs the ping-pong K-loop (full tiles; falls back to lockstep on the ragged shape)."""
+    from chambers_amd import _lib
+    from chambers_amd import kernels as K
+    a = bf(torch.randn(m, k, generator=g(71))).cuda()
+    b = bf(torch.randn(n, k, generator=g(72)) * 0.05).cuda()
+    bias = (torch.randn(n, generator=g(73)) * 0.1).cuda()
+    resid = torch.randn(m, n, generator=g(74)).cuda() if epi == "resid" else None
+    kw = dict(bias=bias, epilogue={"resid": K.EPI_RESID, "none": K.EPI_NONE, "gelu": K.EPI_GELU}[epi], resid=resid,
+              drop_rate=0.1 if epi == "resid" else 0.0, drop_key=9)
+
+    def run():
+        out = torch.full((m, n), float("nan"), dtype=torch.float32 if epi == "resid" else torch.bfloat16, device="cuda")
+        aux = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda") if epi == "gelu" else None
+        K.gemm_nt(a, b, out, aux=aux, **kw)
+        torch.cuda.synchronize()
+        return out, aux
+
+    try:
+        _lib.set_option("GEMM_TILE_QUEUE", 0)
+        ref, ref_aux = run()
+        assert not torch.isnan(ref.float()).any()
+        _lib.set_option("GEMM_TILE_QUEUE", 1)
+        for _ in range(70):
+            out, aux = run()
+            assert torch.equal(out, ref) and (aux is None or torch.equal(aux, ref_aux))
+        _lib.set_option("GEMM_ALGO", 4)
+        for _ in range(3):
+            out, aux = run()
+            assert torch.equal(out, ref) and (aux is None or torch.equal(aux, ref_aux))
+    finally:
+        _lib.set_option("GEMM_ALGO", 0)
+        _lib.set_option("GEMM_TILE_QUEUE", 1)
+
+
 @pytest.mark.parametrize("m,n,k", PERSISTENT_SHAPES)
 @pytest.mark.parametrize("rate", [0.0, 0.1])
 def test_persistent_gemm_residual_dropout(m, n, k, rate):

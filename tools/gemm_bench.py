@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from chambers_amd import _build
+if os.environ.get("CHB_AB_LIB"):        # A/B builds of the library (tools/ab_build.sh), this tool only
+    _build.LIB_PATH = os.path.abspath(os.environ["CHB_AB_LIB"])
 from chambers_amd import _lib, kernels as K
 
 M = 512 * 197

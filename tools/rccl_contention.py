@@ -1,7 +1,8 @@
 """Single-GPU rehearsal of what a collective running beside the backward pass costs the train step.
 
 An RCCL all-reduce is a kernel of a few dozen workgroups that holds its CUs for the length of the exchange.  This tool puts a
-stand-in (tools/cu_hog.hip: n_wg workgroups x 256 threads that spin for a given time, no memory traffic) on a side stream at
+stand-in (tools/cu_hog.hip: n_wg workgroups x 256 threads with 16 KiB of LDS each that stream a 21 MiB buffer, read + write,
+for a given time) on a side stream at
 every point where the engine hands a gradient bucket to the reducer, exactly as ProcessGroupNCCL orders its kernel behind the
 compute stream, and reports the step time with and without it.  Usage:
     python tools/rccl_contention.py [batch] [n_wg] [micros]
@@ -18,11 +19,11 @@ micros = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 
 so = os.path.join(ROOT, "build", "libcu_hog.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-if not os.path.exists(so):
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(ROOT, "tools", "cu_hog.hip")):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so,
                            os.path.join(ROOT, "tools", "cu_hog.hip")])
 hog = ctypes.CDLL(so)
-hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
 
 from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
 
@@ -33,6 +34,7 @@ g = np.random.Generator(np.random.PCG64(0))
 images = torch.as_tensor(g.integers(0, 256, size=(batch, 224, 224, 3), dtype=np.uint8), device="cuda")
 labels = torch.as_tensor(g.integers(0, 1000, size=(batch,)), device="cuda")
 side = torch.cuda.Stream()
+hog_buf = torch.zeros(21 * 1024 * 1024 // 4, dtype=torch.float32, device="cuda")     # one MLP-side gradient bucket
 mode = {"on": False, "placement": "engine"}
 launched = [0]
 
@@ -45,7 +47,7 @@ def launch():
         ev = torch.cuda.Event()
         ev.record()                   # the collective starts once the bucket's gradients are final ...
         side.wait_event(ev)
-        hog.hog_launch(n_wg, micros, ctypes.c_void_p(side.cuda_stream))
+        hog.hog_launch(n_wg, micros, ctypes.c_void_p(hog_buf.data_ptr()), hog_buf.numel() * 4, ctypes.c_void_p(side.cuda_stream))
         launched[0] += 1
     del queued[:]
 
@@ -84,12 +86,17 @@ def run(steps):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-base = run(10)
-mode["on"] = True
-print("batch %d  stand-in collective: %d WGs x %d us per gradient bucket   step alone %.2f ms   GEMM_ALGO=%s"
-      % (batch, n_wg, micros, base, os.environ.get("CHB_GEMM_ALGO", "default")))
-for placement in ("immediate", "engine"):      # immediate: at bucket_ready (behind a persistent GEMM); engine: where the engine flushes
-    mode["placement"] = placement
-    launched[0] = 0
-    t = run(10)
-    print("  placement %-9s %2.0f launches/step   step %.2f ms   (+%.2f ms, %.1f %%)" % (placement, launched[0] / 13, t, t - base, 100 * (t / base - 1)))
+from chambers_amd import _lib
+
+print("batch %d  stand-in collective: %d WGs x %d us per gradient bucket (16 KiB LDS each, streaming a 21 MiB buffer)" % (batch, n_wg, micros))
+for queue in (0, 1):          # static tile shares vs the per-XCD tile queue of the persistent NT GEMM
+    _lib.set_option("GEMM_TILE_QUEUE", queue)
+    mode["on"] = False
+    base = run(10)
+    mode["on"] = True
+    print(" GEMM_TILE_QUEUE=%d   step alone %.2f ms" % (queue, base))
+    for placement in ("immediate", "engine"):      # immediate: at bucket_ready (behind a persistent GEMM); engine: where the engine flushes
+        mode["placement"] = placement
+        launched[0] = 0
+        t = run(10)
+        print("   placement %-9s %2.0f launches/step   step %.2f ms   (+%.2f ms, %.1f %%)" % (placement, launched[0] / 13, t, t - base, 100 * (t / base - 1)))
