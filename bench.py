@@ -129,6 +129,24 @@ def _median_time(fn, warmup, runs, what=""):
     return float(np.median(ts))
 
 
+def host_cores():
+    """The CPU share this process really has: the affinity mask, cut down to the cgroup's CPU quota when there is one and to 16
+    otherwise-unlimited threads (a GPU box shows all 256 hardware threads of its host in the mask but gives a job a share of
+    them; torch with 256 threads on these problem sizes is slower than with 1)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(cfg_kwargs, train_batch=32, runs=5, warmup=2):
     """SURVEY 8(d) / BASELINE.md 4 protocol, on this host: the oracle (fp32 torch-CPU / NumPy restatement of the TF2 reference,
     kind "port") timed as the median of `runs` runs after `warmup` warm-ups, at k = all host cores this process may use and k = 1:
@@ -138,10 +156,7 @@ def cpu_baseline(cfg_kwargs, train_batch=32, runs=5, warmup=2):
     from chambers_amd.engine import ViTConfig, init_keras_weights
     from oracle import augment_ref as A
     from oracle import rng_ref, vit_ref
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     g = np.random.Generator(np.random.PCG64(0))
 
     # ---- config 1: ViT-Ti/16 forward, batch 8

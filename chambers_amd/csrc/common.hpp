@@ -116,7 +116,7 @@ enum ChbOption {
     CHB_OPT_GEMM_WALK,           // 0 linear tile ids per XCD, 1 (default) panel walk where it pays, 2 always panel
     CHB_OPT_TN_ATOMICS,          // 1 = always the atomic epilogue
     CHB_OPT_TN_FAST,             // 0 = generic staging addresses everywhere (default 1)
-    CHB_OPT_GEMM_TILE_QUEUE,     // 1 (default) = persistent NT GEMM workgroups claim their tiles after the first from per-XCD counters, 0 = static tile shares
+    CHB_OPT_GEMM_TILE_QUEUE,     // 1 = persistent NT GEMM workgroups claim their tiles after the first from per-XCD counters (the engine turns it on when it trains data-parallel), 0 (default) = static tile shares
     CHB_OPT_DEBUG,               // timing experiments only (tools/): e.g. 1 = attention backward without its main loop; results are WRONG
     CHB_OPT_COUNT
 };

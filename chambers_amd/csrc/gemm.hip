@@ -375,12 +375,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
     }
 }
 
-// Tile queue of the persistent NT kernel: per launch slot, one counter per XCD (the XCD's tile list is private to its workgroups)
-// and one hand-off word per workgroup (wave 0 claims, the other waves read the claim two barriers later).  Zero at load time; the
-// workgroup that draws an XCD's LAST ticket zeroes its counter again, so a slot is clean whenever its launch has ended.
+// Tile queue of the persistent NT kernel: per launch slot, one counter per XCD (the XCD's tile list is private to its workgroups).
+// Zero at load time; the workgroup that draws an XCD's LAST ticket zeroes its counter again, so a slot is clean whenever its
+// launch has ended.
 constexpr int TILE_QUEUE_SLOTS = 64;
 __device__ int g_tile_ctr[TILE_QUEUE_SLOTS][8];
-__device__ int g_tile_claim[TILE_QUEUE_SLOTS][512];
 
 struct TileWalk {
     int dyn;                        // tile queue on: tile j > 0 of this workgroup is li_tab[j & 3] (claimed), not slot + j*stride
@@ -502,13 +501,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     // Tile queue (K >= 8 K-tiles): a workgroup's first tile is its static one, every later tile is the next ticket of its XCD's
     // counter.  A workgroup that starts late (its CU was held by another stream's kernel - a collective) then simply draws fewer
     // tickets: the launch loses that CU's share of the time it was away, not a whole static tile share at the end.
-    // Tile j + 1 is claimed while tile j is young: wave 0 draws the ticket at the end of K-step 0, hands it over through
-    // g_tile_claim in K-step 2 (the atomic has returned by K-step 1's vmcnt(0)), every wave picks it up in K-step 4 (wave 0's
-    // store is two barriers old) - the staging streams need it from K-step ntk - 2 on.
+    // Tile j + 1 is claimed while tile j is young: wave 0 draws the ticket at the end of K-step k0 = slot & 3, hands it over
+    // in K-step k0 + 1 (the atomic has returned by that step's vmcnt(0)), every wave picks it up in K-step k0 + 2 - the staging
+    // streams need it from K-step ntk - 2 on.
     w.dyn = (p.queue_slot >= 0 && w.ntk >= 8) ? 1 : 0;
+    const int q_k0 = w.slot & 3;      // the XCD's 32 workgroups run in step: spread their draws over four K-steps
     int* q_ctr = &g_tile_ctr[w.dyn ? p.queue_slot : 0][blockIdx.x & 7];
-    int* q_claim = &g_tile_claim[w.dyn ? p.queue_slot : 0][blockIdx.x & 511];
-    int q_ticket = 0, q_seen = 0;
+    int q_ticket = 0;
 
     // lane-constant byte offsets of the two LDS-DMA instructions a wave issues per half-tile (row 64 j + 8 wave + lane / 8)
     uint32_t offa[2], offb[2];
@@ -557,7 +556,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     for (int s = 0; cc.valid; ++s) {
         bf16_t* ring = smem + (s & 1) * 4 * 8192;
         bf16_t* nring = smem + ((s + 1) & 1) * 4 * 8192;
-        if (w.dyn && cc.kt == 4) q_seen = __hip_atomic_load(q_claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // wave-uniform branch
         const bf16_t* As = ring + wm * 8192;
         const bf16_t* Bs = ring + (2 + (wn >> 1)) * 8192;
         bf16x8_t af[4][2], bq[4][2];
@@ -603,12 +601,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A and B half-tiles; step s+1 has landed
         __builtin_amdgcn_sched_barrier(0);
         if (w.dyn) {
-            // the ticket is drawn right behind this step's vmcnt(0), so its round trip (up to ~3 k cycles when every CU draws at
-            // once) has two whole K-steps before a wait covers it - drawn at the top of the step it stalled that step's wait
-            // (inline asm: hipcc's atomicAdd aggregates over the wave and reads the result back at once - an s_waitcnt vmcnt(0)
-            // right behind the atomic, which stalled wave 0 and with it the workgroup for the whole round trip; an asm result is
-            // outside its bookkeeping, the K-loop's own vmcnt(0) of the next step covers it.  Lane 0 only, in-place operand.)
-            if (cc.kt == 0 && wave == 0) {      // scalar branch
+            // The ticket is drawn right behind this step's vmcnt(0): its round trip has a whole K-step before the next vmcnt(0)
+            // has to cover it.  (Inline asm: hipcc's atomicAdd aggregates over the wave and reads the result back at once - an
+            // s_waitcnt vmcnt(0) right behind the atomic, which stalled wave 0 and with it the workgroup for the round trip; an
+            // asm result is outside its bookkeeping.  Lane 0 only, in-place operand.)  The hand-off to the other waves goes
+            // through a word of wave 0's epilogue scratch, idle during the K-loop: global stores / coherent loads would each
+            // sit in a K-step's vmcnt(0) for longer than the LDS-DMA loads that wait is there for (measured: -2...-3 % per GEMM).
+            int* q_lds = reinterpret_cast<int*>(smem + 2 * 4 * 8192);
+            if (cc.kt == q_k0 && wave == 0) {      // scalar branch
                 q_ticket = 1;
                 uint64_t save;
                 asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %[t], %[off], %[t], %[ptr] sc0\n\ts_mov_b64 exec, %[sv]"
@@ -616,14 +616,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
                              : [off] "v"(0), [ptr] "s"(q_ctr)
                              : "memory");
             }
-            if (cc.kt == 2 && wave == 0 && lane == 0) {
+            if (cc.kt == q_k0 + 1 && wave == 0 && lane == 0) {
                 // tickets 0 .. cnt-1 are drawn per XCD and launch (one per tile started): ticket t is tile stride + t of the
                 // XCD's list, and whoever holds the last one leaves the counter clean for the slot's next launch
-                __hip_atomic_store(q_claim, w.stride + q_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *q_lds = w.stride + q_ticket;
                 if (q_ticket == w.cnt - 1) __hip_atomic_store(q_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (cc.kt == 4) {
-                const int nxt = __builtin_amdgcn_readfirstlane(q_seen);
+            if (cc.kt == q_k0 + 2) {               // wave 0's LDS write is one barrier old
+                const int nxt = __builtin_amdgcn_readfirstlane(*q_lds);
                 const int q = (cc.j + 1) & 3;
                 if (q == 0) w.li_tab[0] = nxt; else if (q == 1) w.li_tab[1] = nxt; else if (q == 2) w.li_tab[2] = nxt; else w.li_tab[3] = nxt;
             }

@@ -194,7 +194,7 @@ def test_persistent_gemm_gelu_and_dgelu_colsum(m, n, k, out_f32):
     assert bool((out2[m:].float() == 9.0).all())
 
 
-@pytest.mark.parametrize("m,n,k,epi", [(8192, 1024, 768, "resid"), (8192 + 100, 1280, 512, "none"), (16384, 768, 1024, "gelu"),
+@pytest.mark.parametrize("m,n,k,epi", [(8192, 1024, 768, "resid"), (8192 + 100, 1280, 640, "none"), (16384, 768, 1024, "gelu"),
                                          (4096, 512, 448, "none")])
 def test_persistent_gemm_schedules_agree_bit_for_bit(m, n, k, epi):
     """The same K order and accumulation order in every schedule of the persistent NT kernel: static tile shares vs the per-XCD
@@ -230,7 +230,7 @@ def test_persistent_gemm_schedules_agree_bit_for_bit(m, n, k, epi):
             assert torch.equal(out, ref) and (aux is None or torch.equal(aux, ref_aux))
     finally:
         _lib.set_option("GEMM_ALGO", 0)
-        _lib.set_option("GEMM_TILE_QUEUE", 1)
+        _lib.set_option("GEMM_TILE_QUEUE", 0)
 
 
 @pytest.mark.parametrize("m,n,k", PERSISTENT_SHAPES)
