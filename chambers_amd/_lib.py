@@ -69,6 +69,11 @@ PROTOTYPES = {
     "chb_cast_transpose": [P, P, P, P, c_int, c_int, P],
     "chb_adamw": [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_int, P],
     "chb_zero_f32": [P, c_int64, P],
+    "chb_add_f32": [P, P, P, c_int64, P],
+    "chb_cast_f32_bf16": [P, P, c_int64, P],
+    "chb_cast_bf16_f32": [P, P, c_int64, P],
+    "chb_copy_rows": [P, c_int64, P, c_int64, c_int64, c_int64, P],
+    "chb_softmax_f32": [P, c_int64, P, c_int64, c_int, c_int, P],
     "chb_set_option": [ctypes.c_char_p, c_int],
 }
 INFO_SYMBOLS = ["chb_version", "chb_build_arch"]

@@ -309,6 +309,54 @@ __global__ void __launch_bounds__(256) tanh_bwd_kernel(const float* __restrict__
 
 }  // namespace
 
+// ---- small tensor utilities of the stand-alone layers (Dense(softmax), ConcatEmbedding, EncoderLayer's first residual, operand casts):
+// torch supplies memory, never arithmetic ----
+__global__ void __launch_bounds__(256) add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n4,
+                                                      int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = n4 * 4; i < n; ++i) out[i] = a[i] + b[i];
+}
+
+__global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f32_to_bf16(src[i]);
+}
+
+__global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = bf16_to_f32(src[i]);
+}
+
+// rows x row_bytes, independent strides (bytes): dst[r][0..row_bytes) = src[r][0..row_bytes); one wave per row chunk of 256 bytes
+__global__ void __launch_bounds__(256) copy_rows_kernel(const uint8_t* __restrict__ src, int64_t src_stride, uint8_t* __restrict__ dst,
+                                                        int64_t dst_stride, int64_t rows, int64_t row_bytes) {
+    const int64_t chunks = (row_bytes + 3) / 4;       // dword granules (row_bytes % 4 == 0 and 4-byte alignment are checked on the host)
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks, c = i - r * chunks;
+        reinterpret_cast<uint32_t*>(dst + r * dst_stride)[c] = reinterpret_cast<const uint32_t*>(src + r * src_stride)[c];
+    }
+}
+
+// softmax over the last axis, one wave per row, fp32 (tf.nn.softmax: exp(x - max) / sum)
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ x, int64_t ld, float* __restrict__ out, int64_t ld_out, int rows,
+                                                           int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.0f;
+    for (int c = lane; c < cols; c += 64) sum += expf(xr[c] - m);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    float* orow = out + (int64_t)row * ld_out;
+    for (int c = lane; c < cols; c += 64) orow[c] = expf(xr[c] - m) / sum;
+}
+
 int chb_option(int id) {
     if (id < 0 || id >= CHB_OPT_COUNT) return 0;
     if (!g_option_read[id].load(std::memory_order_acquire)) {
@@ -469,6 +517,49 @@ int chb_adamw(float* p, float* g, float* m, float* v, const uint8_t* decay_flags
     else
         hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, decay_flags, n / 4, lr_t,
                            1.0f - beta1, 1.0f - beta2, eps, weight_decay, grad_scale);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!a || !b || !out || n < 0) return CHB_EINVAL;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return CHB_EINVAL;
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, n);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!src || !dst || n < 0) return CHB_EINVAL;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!src || !dst || n < 0) return CHB_EINVAL;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_copy_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes, int64_t rows, int64_t row_bytes, void* stream) {
+    if (rows == 0 || row_bytes == 0) return CHB_OK;
+    if (!src || !dst || rows < 0 || row_bytes < 0) return CHB_EINVAL;
+    if ((row_bytes & 3) || (src_stride_bytes & 3) || (dst_stride_bytes & 3) || ((uintptr_t)src & 3) || ((uintptr_t)dst & 3)) return CHB_EINVAL;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * (row_bytes / 4))), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src,
+                       src_stride_bytes, (uint8_t*)dst, dst_stride_bytes, rows, row_bytes);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_softmax_f32(const float* x, int64_t ld, float* out, int64_t ld_out, int rows, int cols, void* stream) {
+    if (rows == 0) return CHB_OK;
+    if (!x || !out || rows < 0 || cols <= 0 || ld < cols || ld_out < cols) return CHB_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(chb_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, out, ld_out, rows, cols);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

@@ -532,3 +532,71 @@ def zero_f32(x):
         raise ValueError("zero_f32 expects a contiguous float32 tensor")
     _lib.call("chb_zero_f32", _lib.ptr(x), x.numel(), _s())
     return x
+
+
+# ------------------------------------------------------------------ small tensor utilities (stand-alone layers)
+def add_f32(a, b, out=None):
+    _lib.require_gpu(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape:
+        raise ValueError("add_f32 takes two fp32 tensors of one shape")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a) if out is None else out
+    _lib.call("chb_add_f32", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), _s())
+    return out
+
+
+def cast_bf16(x):
+    """fp32 -> bf16 (round to nearest even), a bf16 tensor is returned as it is."""
+    if x.dtype == torch.bfloat16:
+        return x
+    _lib.require_gpu(x)
+    if x.dtype != torch.float32:
+        raise ValueError("cast_bf16 takes fp32 or bf16, got %s" % x.dtype)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.call("chb_cast_f32_bf16", _lib.ptr(x), _lib.ptr(out), x.numel(), _s())
+    return out
+
+
+def cast_f32(x):
+    if x.dtype == torch.float32:
+        return x
+    _lib.require_gpu(x)
+    if x.dtype != torch.bfloat16:
+        raise ValueError("cast_f32 takes bf16 or fp32, got %s" % x.dtype)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.call("chb_cast_bf16_f32", _lib.ptr(x), _lib.ptr(out), x.numel(), _s())
+    return out
+
+
+def concat_axis1(parts):
+    """[B, n_i, D] tensors of one dtype -> [B, sum n_i, D] (tf.concat(axis=1)) by strided row copies."""
+    _lib.require_gpu(*parts)
+    b, d = parts[0].shape[0], parts[0].shape[2]
+    es = parts[0].element_size()
+    if any(p.dim() != 3 or p.shape[0] != b or p.shape[2] != d or p.dtype != parts[0].dtype for p in parts) or (d * es) % 4:
+        raise ValueError("concat_axis1 takes [B, n_i, D] tensors of one dtype with D * itemsize % 4 == 0")
+    n = sum(int(p.shape[1]) for p in parts)
+    out = torch.empty((b, n, d), dtype=parts[0].dtype, device=parts[0].device)
+    at = 0
+    for p in parts:
+        p = p.contiguous()
+        ni = int(p.shape[1])
+        dst = ctypes.c_void_p(out.data_ptr() + at * d * es)
+        _lib.call("chb_copy_rows", _lib.ptr(p), ni * d * es, dst, n * d * es, b, ni * d * es, _s())
+        at += ni
+    return out
+
+
+def softmax_rows(x):
+    """Softmax over the last axis of an fp32 tensor."""
+    _lib.require_gpu(x)
+    if x.dtype != torch.float32:
+        raise ValueError("softmax_rows takes fp32")
+    x = x.contiguous()
+    cols = int(x.shape[-1])
+    rows = x.numel() // max(cols, 1)
+    out = torch.empty_like(x)
+    _lib.call("chb_softmax_f32", _lib.ptr(x), cols, _lib.ptr(out), cols, rows, cols, _s())
+    return out

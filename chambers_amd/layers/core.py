@@ -26,7 +26,7 @@ def _as2d(x):
 
 
 def _bf16(x):
-    return x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    return K.cast_bf16(x) if x.dtype in (torch.bfloat16, torch.float32) else x.to(torch.bfloat16)
 
 
 class _OperandCache:
@@ -68,7 +68,7 @@ class Dense(Layer):
             if act == "tanh":
                 K.tanh_fwd(out)                # `feature` head (vision_transformer.py:275-278)
             elif act == "softmax":
-                out = torch.softmax(out, dim=-1)   # classifier_activation of the stand-alone layer; training consumes logits
+                out = K.softmax_rows(out)          # classifier_activation of the stand-alone layer; training consumes logits
             elif act not in (None, "linear"):
                 raise ValueError("unsupported activation %r" % (act,))
         return out.reshape(*lead, self.units)

@@ -65,7 +65,7 @@ class EncoderLayer(Layer):
         a = self.multi_head_attention([h, h, h], training=training, key=keys.get("attn"))
         # x = x + dropout1(attn): fused as the residual epilogue's element-wise form
         a = self.dropout1(a, training=training, key=keys.get("proj"))
-        x2 = x2 + a.reshape(b * t, d)
+        x2 = K.add_f32(x2, K.cast_f32(a).reshape(b * t, d))
         h2 = self.norm2(x2.reshape(b, t, d))
         u = self.dense1(h2)
         # dense2 with the residual + dropout fused into the GEMM epilogue

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from ... import engine as E
+from ... import kernels as K
 from ..._keras_like import Layer, Sequential
 from ...augmentations.image_augmentations import ImageNetNormalization
 from ... import initializers
@@ -186,16 +187,15 @@ class Model(Layer):
         `preprocess_input` (ImageNetNormalization 'tf') is fused in front.  Returns float32 logits / features."""
         eng = self.engine(inputs.shape[0], training=False)
         if inputs.dtype != torch.uint8:
-            from ... import kernels as K
             K.patchify_f32(inputs.to(torch.float32), self.cfg.patch_size, out=eng.patches)
             out = eng.forward(None, training=bool(training), prepatched=True)
         else:
             out = eng.forward(inputs, training=bool(training))
         soft = getattr(self, "classifier_activation", None) == "softmax"
         if isinstance(out, tuple):                        # distilled variant: [x_cls, x_dist] (vision_transformer.py:392-393)
-            return [torch.softmax(o.float(), dim=-1) if soft else o.clone() for o in out]
+            return [K.softmax_rows(K.cast_f32(o)) if soft else o.clone() for o in out]
         if soft:
-            return torch.softmax(out.float(), dim=-1)     # B x classes; training consumes logits (fused softmax-CE)
+            return K.softmax_rows(K.cast_f32(out))        # B x classes; training consumes logits (fused softmax-CE)
         return out.clone()
 
     predict = call

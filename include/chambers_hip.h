@@ -314,6 +314,17 @@ int chb_set_option(const char* name, int value);
 /* x[0..n) = 0 (n % 4 == 0, 16-byte aligned): gradient buffer reset when backward runs twice without an optimizer step. */
 int chb_zero_f32(float* x, int64_t n, void* stream);
 
+/* Small tensor utilities of the stand-alone Keras-style layers (torch allocates, this library computes):
+ * out = a + b (fp32, 16-byte aligned) - the first residual of EncoderLayer.call (layers/transformer.py:72-74);
+ * fp32 <-> bf16 casts of GEMM operands; a strided 2-D copy (rows x row_bytes; all strides, sizes and pointers multiples of 4) -
+ * ConcatEmbedding's tf.concat (layers/embedding.py:100-104); softmax over the last axis of fp32 rows - the classifier_activation
+ * of the stand-alone Dense / of model.predict (vision_transformer.py:283). */
+int chb_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int chb_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int chb_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
+int chb_copy_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes, int64_t rows, int64_t row_bytes, void* stream);
+int chb_softmax_f32(const float* x, int64_t ld, float* out, int64_t ld_out, int rows, int cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -727,3 +727,24 @@ def test_cast_transpose_and_adamw():
         K.adamw(p, grad.cuda(), mm, vv, flags, float(lr_t), 0.9, 0.999, 1e-7, 0.05)
     ref = torch.cat([params["a"], params["b"]])
     assert torch.allclose(p.cpu(), ref, rtol=2e-6, atol=1e-7), float((p.cpu() - ref).abs().max())
+
+
+def test_tensor_utilities_of_the_standalone_layers():
+    """chb_add_f32 / chb_cast_* / chb_copy_rows / chb_softmax_f32: the arithmetic the stand-alone Keras-style layers used to ask torch for."""
+    from chambers_amd import kernels as K
+    a = torch.randn(1027, 33, generator=g(81)).cuda()
+    b = torch.randn(1027, 33, generator=g(82)).cuda()
+    assert torch.equal(K.add_f32(a, b), a + b)
+    assert torch.equal(K.cast_bf16(a), a.to(torch.bfloat16))
+    assert torch.equal(K.cast_f32(K.cast_bf16(a)), a.to(torch.bfloat16).float())
+    parts = [torch.randn(5, n, 64, generator=g(83 + n)).cuda() for n in (1, 196, 2)]
+    assert torch.equal(K.concat_axis1(parts), torch.cat(parts, dim=1))
+    x = (torch.randn(37, 1000, generator=g(90)) * 4).cuda()
+    got = K.softmax_rows(x)
+    ref = torch.softmax(x.double(), dim=-1)
+    assert float((got.double() - ref).abs().max()) < 3.6e-7 and float((got.sum(-1) - 1).abs().max()) < 1e-5      # fp32 expf: measured 2.4e-7
+    from chambers_amd.layers.embedding import ConcatEmbedding
+    layer = ConcatEmbedding(1, 64, side="left", axis=1)
+    tokens = torch.randn(3, 10, 64, generator=g(91)).cuda()
+    out = layer(tokens)
+    assert out.shape == (3, 11, 64) and torch.equal(out[:, 1:], tokens) and torch.equal(out[:, 0], layer.embedding.value.expand(3, 64))
