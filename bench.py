@@ -93,6 +93,22 @@ class KernelTimer:
         return {k: {"launches": v[0], "total_ms": v[1], "avg_us": 1e3 * v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12,
                     "work": v[2]} for k, v in agg.items()}
 
+    def union_ms(self):
+        """Wall time during which at least one timed launch was running: launches of two streams overlap (the engine runs
+        weight-gradient GEMMs beside the dgrad chain), so the sum of durations counts shared time twice."""
+        if not self.records:
+            return 0.0
+        base = self.records[0][2]
+        iv = sorted((base.elapsed_time(s), base.elapsed_time(e)) for _n, _w, s, e in self.records)
+        total, cur_a, cur_b = 0.0, iv[0][0], iv[0][1]
+        for a, b in iv[1:]:
+            if a > cur_b:
+                total += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        return total + (cur_b - cur_a)
+
     @staticmethod
     def families(ks):
         """Template instantiations of one kernel (gemm_nt256_kernel<EPI, OUT>) belong to one family: the dominant kernel of
@@ -412,8 +428,19 @@ def main():
                          "unit": "TFLOP/s", "frac": fams[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_us": fams[dom]["avg_us"], "launches": fams[dom]["launches"],
                          "algorithmic_flop_per_launch": fams[dom]["work"] / fams[dom]["launches"],
+                         "note": ("launch durations include time shared with the weight-gradient GEMMs of the engine's second stream "
+                                  "(overlap_wgrad); see mfma_all_gemms; the default (CHB_OVERLAP_WGRAD unset) runs one stream")
+                         if getattr(eng, "overlap_wgrad", False) else "one stream: launches do not overlap",
                          "families": {k: {"total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 1), "launches": v["launches"],
                                           "frac": round(v["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)} for k, v in fams.items()}},
+            # all GEMM launches together: their FLOPs over the wall time in which at least one of them ran.  The engine issues a
+            # block's weight-gradient GEMMs on a second stream beside the dgrad chain (they fill launch tails, launch gaps and
+            # the bandwidth-bound kernels' idle MFMA pipes) when CHB_OVERLAP_WGRAD=1; a launch's own duration - what `roofline` prices, as
+            # the contract says - then includes time in which it shared the chip.  Default: one stream, the two numbers agree
+            "mfma_all_gemms": {"tflops": sum(v["work"] for v in fams.values()) / (timer.union_ms() * 1e-3) / 1e12,
+                               "frac": sum(v["work"] for v in fams.values()) / (timer.union_ms() * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                               "busy_ms_per_step": timer.union_ms() / args.steps,
+                               "overlap_wgrad": bool(getattr(eng, "overlap_wgrad", False))},
             "step_tflops": train_flops / (ms_per_step * 1e-3) / 1e12,
             "step_frac_of_mfma_peak": train_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "kernels": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 1), "launches": v["launches"],

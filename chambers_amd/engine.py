@@ -19,6 +19,7 @@ earlier blocks are still in backward.  Two bf16 images of the matrices are refre
 optimizer step: [K][N] (B operand of dgrad) and its transpose [N][K] (B operand of forward).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -377,9 +378,36 @@ class GradBucketReducer:
         return 1.0 / self.world
 
 
+class _SideRing:
+    """Same-shaped buffers written on the main stream and read by launches on a side stream: `acquire()` hands out the next slot
+    for writing once the side stream's last read of it is done; `mark_read(stream)` notes a read just enqueued there."""
+
+    def __init__(self, bufs):
+        self.bufs = list(bufs)
+        self.i = 0
+        self.read_ev = [None] * len(self.bufs)
+
+    @property
+    def cur(self):
+        return self.bufs[self.i]
+
+    def acquire(self):
+        self.i = (self.i + 1) % len(self.bufs)
+        ev = self.read_ev[self.i]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.read_ev[self.i] = None
+        return self.bufs[self.i]
+
+    def mark_read(self, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.read_ev[self.i] = ev
+
+
 # ---------------------------------------------------------------------------------------------
 class ViTEngine:
-    def __init__(self, cfg, batch_size, device=None, training=True, seed=0, decay_fn=None, process_group=None):
+    def __init__(self, cfg, batch_size, device=None, training=True, seed=0, decay_fn=None, process_group=None, overlap_wgrad=None):
         if not torch.cuda.is_available():
             raise RuntimeError("ViTEngine needs an MI355X (torch.cuda is not available); there is no CPU fallback")
         self.cfg, self.B, self.training, self.seed = cfg, int(batch_size), bool(training), int(seed)
@@ -415,6 +443,7 @@ class ViTEngine:
         self.ct_n = len(mats)
         self.ct_tiles = max(((s.shape[0] + 63) // 64) * ((s.shape[1] + 63) // 64) for s in mats)
         self.opt_step = 0
+        self._overlap_arg = overlap_wgrad
         self._alloc_activations()
 
     def _upload_decay_flags(self):
@@ -539,6 +568,22 @@ class ViTEngine:
             self.dqkv = z(Mp, 3 * d)
             # scratch for the split-K partial planes of the weight-gradient GEMMs (one launch at a time on the stream)
             self.tn_ws = torch.empty(max(K.tn_workspace_elems(*sp.shape) for sp in self.specs if sp.matrix), dtype=f32, device=dev)
+            # Weight gradients on a side stream (overlap_wgrad): a block's four wgrad GEMMs depend only on saved activations and on
+            # dz / da1 / dqkv, and nothing but the optimizer reads their output, so they need not sit in the dgrad chain.  Kernels
+            # of ONE stream are separated by full barriers - a launch's tail (4.6 rounds of tiles on the N = 768 GEMMs), the ~6 us
+            # between dependent launches and the bandwidth-bound LayerNorm / latency-bound attention backward leave CUs idle that
+            # an independent MFMA-bound launch of another stream fills.  The three operands get small rings so the side stream
+            # may run up to a block behind; it has its own split-K scratch.
+            # Measured (bench.py, same box, A/B): 73.1 -> 71.7 ms/step on two boxes, 75.6 -> 75.0 on a third (+0.8 ... +1.9 %).  Off
+            # by default: every launch's duration then includes time it shared the chip, which makes per-kernel timings (the
+            # rooflines in profiles/) unreadable - opt in with CHB_OVERLAP_WGRAD=1 or ViTEngine(..., overlap_wgrad=True).
+            self.overlap_wgrad = bool(int(os.environ.get("CHB_OVERLAP_WGRAD", "0"))) if self._overlap_arg is None else bool(self._overlap_arg)
+            if self.overlap_wgrad:
+                self.side = torch.cuda.Stream(device=dev)
+                self.tn_ws_side = torch.empty_like(self.tn_ws)
+                self.dz_ring = _SideRing([self.dz, z(Mp, d), z(Mp, d), z(Mp, d)])
+                self.da1_ring = _SideRing([self.da1, z(Mp, ff)])
+                self.dqkv_ring = _SideRing([self.dqkv, z(Mp, 3 * d)])
             self.dpatch = z(self.Mpatch_p, d)
             self.labels = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
 
@@ -737,44 +782,73 @@ class ViTEngine:
             K.layernorm_bwd(self.dh, self.x_final, d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, d, False,
                             self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), M, d)
         self.reducer.bucket_ready(0)
+        side = self.side if self.overlap_wgrad else None
+
+        def nxt(name):          # next buffer of an operand the side stream reads (a ring slot, or the one buffer)
+            if side is None:
+                return getattr(self, name)
+            buf = getattr(self, name + "_ring").acquire()
+            setattr(self, name, buf)      # the attribute always names the latest version (tests and tools read it after backward)
+            return buf
+
+        def wgrad(x, name, gname, colsum=None):
+            dy = getattr(self, name)
+            if side is None:
+                K.gemm_tn(x, dy, self.g(gname), m=Mp, ws=self.tn_ws, colsum=colsum)
+                return
+            ev = torch.cuda.Event()
+            ev.record()                   # dy is final on the main stream
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                K.gemm_tn(x, dy, self.g(gname), m=Mp, ws=self.tn_ws_side, colsum=colsum)
+            getattr(self, name + "_ring").mark_read(side)
+
+        def join():               # gradients written on the side stream are final for whatever the main stream does next
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+
         # dz of the last block's MLP branch (afterwards every LayerNorm backward emits the next dz + its bias gradient)
-        K.dropout_bwd(self.dx, self.dz, M, d, rate, key(rng.site_mlp(L - 1)))
+        K.dropout_bwd(self.dx, nxt("dz"), M, d, rate, key(rng.site_mlp(L - 1)))
         K.colsum(self.dz, self.g("encoder/layer_%d/dense2/bias" % (L - 1)), m=M)
         for l in reversed(range(L)):
             a = self.acts[l]
             pre = "encoder/layer_%d/" % l
             # MLP branch (self.dz = dropout-backward of dx at site_mlp(l))
-            K.gemm_tn(a["u"], self.dz, self.g(pre + "dense2/kernel"), m=Mp, ws=self.tn_ws)
-            K.gemm_nt(self.dz, self.wb(pre + "dense2/kernel"), self.da1, m=M, epilogue=K.EPI_DGELU, aux=a["a1"],
+            wgrad(a["u"], "dz", pre + "dense2/kernel")
+            dz = self.dz
+            K.gemm_nt(dz, self.wb(pre + "dense2/kernel"), nxt("da1"), m=M, epilogue=K.EPI_DGELU, aux=a["a1"],
                       colsum=self.g(pre + "dense1/bias"))           # bias gradient of dense1 fused into the epilogue
-            K.gemm_tn(a["h2"], self.da1, self.g(pre + "dense1/kernel"), m=Mp, ws=self.tn_ws)
+            wgrad(a["h2"], "da1", pre + "dense1/kernel")
             K.gemm_nt(self.da1, self.wb(pre + "dense1/kernel"), self.dh, m=M)
             K.layernorm_bwd(self.dh, a["xmid"], d, a["mean2"], a["rstd2"], self.p(pre + "norm2/gamma"), self.dx, d, True,
-                            self.g(pre + "norm2/gamma"), self.g(pre + "norm2/beta"), M, d, dz=self.dz,
+                            self.g(pre + "norm2/gamma"), self.g(pre + "norm2/beta"), M, d, dz=nxt("dz"),
                             dz_colsum=self.g(pre + "proj/bias"), drop_rate=rate, drop_key=key(rng.site_proj(l)))
             # attention branch (self.dz = dropout-backward of dx at site_proj(l))
-            K.gemm_tn(a["o"], self.dz, self.g(pre + "proj/kernel"), m=Mp, ws=self.tn_ws)
+            wgrad(a["o"], "dz", pre + "proj/kernel")
             K.gemm_nt(self.dz, self.wb(pre + "proj/kernel"), self.do, m=M)
             # this block's MLP / projection gradients and the previous block's QKV gradients are final and adjacent in the flat
             # buffer: one all-reduce, started beside the attention backward
             self.reducer.bucket_ready(2 * (L - l) - 1)
+            if self.reducer.active:
+                join()            # the collective reads gradients the side stream wrote
             self.reducer.flush()
-            K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], self.dqkv, self.B, n, cfg.n_heads, cfg.head_dim, rate,
+            K.attention_bwd(a["qkv"], a["o"], self.do, a["lse"], nxt("dqkv"), self.B, n, cfg.n_heads, cfg.head_dim, rate,
                             key(rng.site_attn(l)), drop_bits=a["drop_bits"] if rate else None)
             # the QKV bias gradient (column sums of dqkv) rides along in the weight-gradient GEMM as ones^T . dqkv: +5 % on that
             # launch instead of a 0.09 ms pass over dqkv (attention_bwd can also fuse it via dbias=, but its four extra
             # accumulators and the cross-wave fold make the 128-register kernel spill: 0.99 ms against 0.69)
-            K.gemm_tn(a["h1"], self.dqkv, self.g(pre + "qkv/kernel"), m=Mp, ws=self.tn_ws, colsum=self.g(pre + "qkv/bias"))
+            wgrad(a["h1"], "dqkv", pre + "qkv/kernel", colsum=self.g(pre + "qkv/bias"))
             K.gemm_nt(self.dqkv, self.wb(pre + "qkv/kernel"), self.dh, m=M)
             if l > 0:
                 K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
-                                self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d, dz=self.dz,
+                                self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d, dz=nxt("dz"),
                                 dz_colsum=self.g("encoder/layer_%d/dense2/bias" % (l - 1)), drop_rate=rate,
                                 drop_key=key(rng.site_mlp(l - 1)))
             else:
                 K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
                                 self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d)
             self.reducer.bucket_ready(2 * (L - l))
+        join()                    # AdamW (and the last collective) read every gradient
         # embedding stage
         K.embed_bwd(self.dx, self.dpatch, self.g("pos_embedding/embeddings"), self.g("add_cls_token/embeddings"), self.B, n, d, rate,
                     key(rng.SITE_EMBED), n_special=cfg.n_special)

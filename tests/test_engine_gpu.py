@@ -363,3 +363,32 @@ def test_full_size_gemm_linearity_and_wgrad_identity():
     lhs = float(dw.double().sum())
     rhs = float((x.double().sum(1) * dy.double().sum(1)).sum())
     assert abs(lhs - rhs) <= 1e-6 * float((x.double().abs().sum(1) * dy.double().abs().sum(1)).sum())
+
+
+def test_side_stream_weight_gradients_change_nothing():
+    """overlap_wgrad=True runs a block's four weight-gradient GEMMs on a second stream (operand rings, events both ways): same
+    kernels, same operands per gradient - the flat gradient agrees to the order of the fp32 atomics that fold bias-gradient column
+    sums (the only run-to-run freedom of a backward pass).  Several passes back to back, so that ring slots are re-used while the
+    side stream may still be reading them.  (Parameters are not stepped: Adam turns a rounding-noise sign flip of a structurally
+    zero gradient - b_key - into a full +-lr update, which would make two correct runs drift apart.)"""
+    from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
+    cfg = ViTConfig(patch_size=16, patch_dim=256, n_encoder_layers=5, n_heads=4, ff_dim=1024, image_size=(96, 96), classes=16, dropout_rate=0.1)
+    kw = init_keras_weights(cfg, seed=5)
+    g = np.random.Generator(np.random.PCG64(9))
+    labels = torch.as_tensor(g.integers(0, 16, size=(48,)).astype(np.int32), device="cuda")
+    batches = [torch.as_tensor(g.integers(0, 256, size=(48, 96, 96, 3), dtype=np.uint8), device="cuda") for _ in range(4)]
+    grads = []
+    for overlap in (False, True):
+        eng = ViTEngine(cfg, 48, training=True, seed=3, overlap_wgrad=overlap)
+        eng.load_keras_weights(kw)
+        assert eng.overlap_wgrad is overlap
+        out = []
+        for images in batches:
+            eng.forward(images, training=True)
+            eng.loss(labels)
+            eng.backward()
+            out.append(eng.G.clone())
+        torch.cuda.synchronize()
+        grads.append(out)
+    for a, b in zip(*grads):
+        assert float(a.abs().max()) > 0 and rel_l2(b.cpu(), a.cpu()) < 1e-6

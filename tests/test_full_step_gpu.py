@@ -28,8 +28,8 @@ def test_config3_gradient_is_linear_over_the_batch():
     images = torch.as_tensor(g.integers(0, 256, size=(512, 224, 224, 3), dtype=np.uint8), device="cuda")
     labels = torch.as_tensor(g.integers(0, 1000, size=(512,)).astype(np.int32), device="cuda")
 
-    def grads(batch, sl):
-        eng = ViTEngine(cfg, batch, training=True, seed=0)
+    def grads(batch, sl, overlap=False):
+        eng = ViTEngine(cfg, batch, training=True, seed=0, overlap_wgrad=overlap)
         eng.load_keras_weights(kw)
         out = []
         for s in sl:
@@ -52,6 +52,10 @@ def test_config3_gradient_is_linear_over_the_batch():
     # d(mean over 512) = (d(mean over first 256) + d(mean over second 256)) / 2; the weight-gradient GEMMs split the token axis
     # differently for the two batch sizes, so the fp32 sums differ in order only (measured 4.65e-7; bound = x 1.5)
     fp_check("config3 full step | gradient linearity over the batch", rel_l2(g_full, 0.5 * (g_a + g_b)), 7e-7)
+    # the same backward with the weight-gradient GEMMs on the side stream (persistent kernels, operand rings re-used over 12 blocks)
+    (loss_ov, g_ov), = grads(512, [slice(0, 512)], overlap=True)
+    assert torch.equal(loss_ov, loss_full)
+    fp_check("config3 full step | gradient, side-stream weight gradients vs one stream", rel_l2(g_ov, g_full), 3e-7)      # measured 1.9e-7: the order of the bias-gradient atomics
 
 
 def test_config3_train_steps_reduce_the_loss():
