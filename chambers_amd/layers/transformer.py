@@ -53,14 +53,24 @@ class EncoderLayer(Layer):
     def call(self, inputs, mask=None, training=None, keys=None, **kwargs):
         if mask is not None:
             raise ValueError("attention masks are not on the ViT path")
-        if not self.pre_norm:
-            raise NotImplementedError("post-norm EncoderLayer (pre_norm=False) is not on the ViT path (vision_transformer.py:269); "
-                                      "the MI355X kernels implement the pre-norm block")
         keys = keys or {}
         rate = self.dense_dropout_rate if training else 0.0
         x = inputs.to(torch.float32).contiguous()
         b, t, d = x.shape
         x2 = x.reshape(b * t, d)
+        if not self.pre_norm:
+            # the reference's default, layers/transformer.py:59-61: x = norm1(x + attn(x)); x = norm2(x + mlp(x)).  Same kernels as the
+            # pre-norm block (the ViT's), composed the other way round; the residual of the MLP branch rides in dense2's epilogue.
+            a = self.multi_head_attention([x, x, x], training=training, key=keys.get("attn"))
+            a = self.dropout1(a, training=training, key=keys.get("proj"))
+            x1 = self.norm1(K.add_f32(x2, K.cast_f32(a).reshape(b * t, d)).reshape(b, t, d))
+            x1 = K.cast_f32(x1).reshape(b * t, d).contiguous()
+            u = self.dense1(x1.reshape(b, t, d))
+            y = torch.empty((b * t, d), dtype=torch.float32, device=x.device)
+            K.gemm_nt(_bf16(u.reshape(b * t, self.ff_dim)).contiguous(), self.dense2._cache.get(self.dense2, self.dense2.kernel), y,
+                      bias=self.dense2.bias.value, epilogue=K.EPI_RESID, resid=x1, drop_rate=rate,
+                      drop_key=(keys.get("mlp") or _next_key(self._site)) if rate else 0)
+            return K.cast_f32(self.norm2(y.reshape(b, t, d))).reshape(b, t, d)
         h = self.norm1(x)
         a = self.multi_head_attention([h, h, h], training=training, key=keys.get("attn"))
         # x = x + dropout1(attn): fused as the residual epilogue's element-wise form

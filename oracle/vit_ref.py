@@ -239,6 +239,21 @@ def encoder_layer(x, p, prefix, cfg, keys, layer, bf16, taps=None):
     return out
 
 
+def encoder_layer_post_norm(x, p, prefix, cfg, keys, layer, bf16):
+    """EncoderLayer.call post-norm branch (the reference's default, pre_norm=False), layers/transformer.py:59-61,65-77:
+    x = norm1(x + dropout1(attn(x))); x = norm2(x + dropout2(dense2(gelu(dense1(x)))))."""
+    rate = cfg["dropout_rate"]
+    eps = cfg.get("norm_epsilon", 1e-6)
+    a = multi_head_attention(x, p, prefix + "multi_head_attention/", cfg["n_heads"], rate, keys.get(site_attn(layer)), bf16)
+    # bf16=True mirrors the build's storage points: the LayerNorm kernel writes bf16 (in the pre-norm block that is a GEMM operand
+    # anyway; here it is also the residual stream and the block's output)
+    x = _bf(layer_norm(x + _drop(a, rate, keys.get(site_proj(layer))), p[prefix + "norm1/gamma"], p[prefix + "norm1/beta"], eps), bf16)
+    a1 = torch.matmul(x, _bf(p[prefix + "dense1/kernel"], bf16)) + p[prefix + "dense1/bias"]
+    u = _bf(gelu(a1), bf16)
+    y = torch.matmul(u, _bf(p[prefix + "dense2/kernel"], bf16)) + p[prefix + "dense2/bias"]
+    return _bf(layer_norm(x + _drop(y, rate, keys.get(site_mlp(layer))), p[prefix + "norm2/gamma"], p[prefix + "norm2/beta"], eps), bf16)
+
+
 def patch_embed(images, kernel, bias, patch, bf16):
     """Conv2D(D, kernel=p, stride=p, 'valid') + Reshape([-1, D])
     (vision_transformer.py:235-248); kernel is HWIO [p, p, C, D]."""

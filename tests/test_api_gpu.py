@@ -56,8 +56,16 @@ def test_encoder_layer_and_encoder_match_oracle():
     cfg = {"dropout_rate": 0.0, "n_heads": heads, "norm_epsilon": 1e-6}
     ref = vit_ref.encoder_layer(x, p, "encoder/layer_0/", cfg, {}, 0, True)
     assert rel_l2(out, ref) < 4e-3
-    with pytest.raises(NotImplementedError):
-        EncoderLayer(embed_dim=d, num_heads=heads, ff_dim=ff, pre_norm=False)(x.cuda())
+    # the reference's default block (pre_norm=False, layers/transformer.py:59-61): same weights, post-norm composition
+    el_post = EncoderLayer(embed_dim=d, num_heads=heads, ff_dim=ff)
+    assert el_post.pre_norm is False
+    el_post(x.cuda(), training=False)
+    el_post.set_weights(w)
+    out_post = el_post(x.cuda(), training=False)
+    ref_post = vit_ref.encoder_layer_post_norm(x, p, "encoder/layer_0/", cfg, {}, 0, True)
+    assert rel_l2(out_post, ref_post) < 4e-3 and rel_l2(out_post, ref) > 0.1
+    with pytest.raises(ValueError):
+        el_post(x.cuda(), mask=torch.ones(b, t, dtype=torch.bool, device="cuda"))      # attention masks are not built
     enc = Encoder(d, heads, ff, 2, pre_norm=True, norm_output=True)
     y = enc(x.cuda(), training=False)
     assert tuple(y.shape) == (b, t, d) and len(enc.get_weights()) == 2 * 16 + 2
