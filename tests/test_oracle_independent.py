@@ -1,0 +1,157 @@
+"""CPU tier: the oracle against INDEPENDENT implementations of the same published algorithms (not the reference, which cannot run
+here - SURVEY 8c - but third-party code written by other people):
+
+  * Pillow.  The AutoAugment / RandAugment colour ops were defined through PIL (`ImageOps`, `ImageEnhance`); the TF / TFA functions
+    the reference calls are ports that say so in their docstrings.  Invert, Posterize, Solarize, Equalize, AutoContrast and
+    Brightness must agree with Pillow BIT FOR BIT (same integer / truncation arithmetic); Color and Sharpness agree to one grey
+    level (Pillow's luma conversion is integer ITU-R 601 and its SMOOTH filter rounds, TF's are the float forms the oracle restates).
+    Contrast is not compared: the reference's degenerate "mean" is its own quirk (pixels / 256), not PIL's mean.
+  * torch's own operators for the ViT pieces: exact-erf GELU, LayerNorm, softmax attention, Adam with decoupled weight decay.
+An oracle function that drifted from its published algorithm fails here even though the HIP path (checked against the oracle)
+would still pass."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_ref as A
+from oracle import vit_ref
+
+PIL = pytest.importorskip("PIL")
+from PIL import Image, ImageEnhance, ImageOps      # noqa: E402
+
+
+def _images():
+    g = np.random.Generator(np.random.PCG64(7))
+    out = []
+    for shape in [(64, 48), (33, 50), (224, 224)]:
+        x = g.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+        out.append(x)
+        lo = x.copy()
+        lo[: shape[0] // 2] = lo[: shape[0] // 2] // 3 + 40          # a low-contrast half: AutoContrast / Equalize do real work
+        out.append(lo)
+    out.append(np.full((16, 16, 3), 93, dtype=np.uint8))             # constant image: the identity branches
+    return out
+
+
+def _pil(x):
+    return Image.fromarray(x)
+
+
+@pytest.mark.parametrize("name,ours,theirs", [
+    ("Invert", lambda x: A.invert(x), lambda im: ImageOps.invert(im)),
+    ("Posterize(3 bits)", lambda x: A.posterize(x, 3), lambda im: ImageOps.posterize(im, 3)),
+    ("Posterize(1 bit)", lambda x: A.posterize(x, 1), lambda im: ImageOps.posterize(im, 1)),
+    ("Solarize(230)", lambda x: A.solarize(x, 230), lambda im: ImageOps.solarize(im, 230)),
+    ("Solarize(0)", lambda x: A.solarize(x, 0), lambda im: ImageOps.solarize(im, 0)),
+    ("Equalize", lambda x: A.equalize(x), lambda im: ImageOps.equalize(im)),
+    ("AutoContrast", lambda x: A.autocontrast(x), lambda im: ImageOps.autocontrast(im)),
+    ("Brightness(1.72)", lambda x: A.brightness(x, 1.72), lambda im: ImageEnhance.Brightness(im).enhance(1.72)),
+    ("Brightness(0.28)", lambda x: A.brightness(x, 0.28), lambda im: ImageEnhance.Brightness(im).enhance(0.28)),
+])
+def test_colour_ops_equal_pillow_bit_for_bit(name, ours, theirs):
+    for x in _images():
+        got = ours(x[None])[0]
+        ref = np.asarray(theirs(_pil(x)))
+        assert np.array_equal(got, ref), "%s differs from Pillow on a %s image: %d pixels" % (name, x.shape, int((got != ref).sum()))
+
+
+@pytest.mark.parametrize("name,ours,theirs", [
+    ("Color(1.72)", lambda x: A.color(x, 1.72), lambda im: ImageEnhance.Color(im).enhance(1.72)),
+    ("Color(0.28)", lambda x: A.color(x, 0.28), lambda im: ImageEnhance.Color(im).enhance(0.28)),
+    ("Sharpness(1.72)", lambda x: A.sharpness(x, 1.72), lambda im: ImageEnhance.Sharpness(im).enhance(1.72)),
+    ("Sharpness(0.28)", lambda x: A.sharpness(x, 0.28), lambda im: ImageEnhance.Sharpness(im).enhance(0.28)),
+])
+def test_colour_ops_within_one_level_of_pillow(name, ours, theirs):
+    for x in _images():
+        got = ours(x[None])[0].astype(np.int32)
+        ref = np.asarray(theirs(_pil(x))).astype(np.int32)
+        d = np.abs(got - ref)
+        assert d.max() <= 1 and (d == 0).mean() > 0.6, "%s vs Pillow on %s: max %d, exact %.3f" % (name, x.shape, d.max(), (d == 0).mean())
+
+
+def test_gelu_layernorm_and_attention_equal_torch_operators():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 37, 96, generator=g) * 3
+    assert torch.allclose(vit_ref.gelu(x), torch.nn.functional.gelu(x), rtol=0, atol=2e-6)            # exact-erf GELU (activations.py:46-56)
+    gamma, beta = torch.randn(96, generator=g), torch.randn(96, generator=g)
+    assert torch.allclose(vit_ref.layer_norm(x, gamma, beta, 1e-6), torch.nn.functional.layer_norm(x, (96,), gamma, beta, 1e-6), rtol=0, atol=3e-6)
+    heads, hd = 3, 32
+    p = {"w_query": torch.randn(96, heads, hd, generator=g) * 0.1, "b_query": torch.randn(heads, 1, hd, generator=g) * 0.1,
+         "w_key": torch.randn(96, heads, hd, generator=g) * 0.1, "b_key": torch.randn(heads, 1, hd, generator=g) * 0.1,
+         "w_value": torch.randn(96, heads, hd, generator=g) * 0.1, "b_value": torch.randn(heads, 1, hd, generator=g) * 0.1,
+         "w_projection": torch.randn(heads, 96, hd, generator=g) * 0.1, "b_projection": torch.randn(1, 96, generator=g) * 0.1}
+    ours = vit_ref.multi_head_attention(x, p, "", heads, 0.0, None, False)
+    q = torch.einsum("btd,dnh->bnth", x, p["w_query"]) + p["b_query"]
+    k = torch.einsum("btd,dnh->bnth", x, p["w_key"]) + p["b_key"]
+    v = torch.einsum("btd,dnh->bnth", x, p["w_value"]) + p["b_value"]
+    o = torch.nn.functional.scaled_dot_product_attention(q, k, v)                                     # softmax(q k^T / sqrt(hd)) v
+    theirs = torch.einsum("bnth,ndh->btd", o, p["w_projection"]) + p["b_projection"]
+    assert torch.allclose(ours, theirs, rtol=0, atol=2e-5)
+
+
+def test_adamw_equals_torch_adamw_with_the_references_decay_convention():
+    """keras Adam + the reference's decoupled decay `var -= wd * var` (optimizers.py:147-155: wd is NOT scaled by lr) against
+    torch.optim.AdamW, whose decay is `var *= 1 - lr * wd` (so its weight_decay = wd / lr) and whose epsilon sits beside
+    sqrt(v / (1 - b2^t)) instead of sqrt(v) - keras' epsilon is in effect eps / sqrt(1 - b2^t) = 3e-6 at step 1, which shows only
+    on the few elements whose gradient is that small (update differs by up to 1.5 % of lr there: measured max 1.5e-5 at lr 1e-3,
+    0.05 % of elements above 2e-6)."""
+    g = torch.Generator().manual_seed(5)
+    w0 = torch.randn(257, 33, generator=g)
+    grads = [torch.randn(257, 33, generator=g) for _ in range(5)]
+    lr, wd = 1e-3, 0.05
+    ours = {"w": w0.clone()}
+    m, v = {"w": torch.zeros_like(w0)}, {"w": torch.zeros_like(w0)}
+    ref = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.AdamW([ref], lr=lr, betas=(0.9, 0.999), eps=1e-7, weight_decay=wd / lr)
+    for t, gr in enumerate(grads, start=1):
+        vit_ref.adamw_step(ours, {"w": gr}, m, v, t, lr=lr, eps=1e-7, weight_decay=wd)
+        ref.grad = gr.clone()
+        opt.step()
+        d = (ours["w"] - ref.detach()).abs()
+        assert float(d.max()) < 0.03 * lr and float((d > 2e-6).float().mean()) < 2e-3 and float(d.mean()) < 2e-7, t
+    assert float((ours["w"] - w0).abs().max()) > 1e-3 * math.sqrt(2)
+
+
+@pytest.mark.parametrize("name", ["ShearX", "ShearY", "TranslateX", "TranslateY", "Rotate", "Rotate (negated)"])
+def test_warps_equal_scipy_ndimage_away_from_the_half_pixel_border(name):
+    """tfa.image.transform semantics as restated by the oracle (output pixel -> input coordinate through the 8-float row, nearest
+    neighbour, constant fill 128) against scipy.ndimage.affine_transform(order=0, mode='constant'): identical on every pixel whose
+    source coordinate is not within half a pixel OUTSIDE the image - there scipy fills (it tests the unrounded coordinate) while
+    TFA rounds first and keeps the edge pixel, which stays the oracle's upstream-recalled choice."""
+    ndimage = pytest.importorskip("scipy.ndimage")
+    g = np.random.Generator(np.random.PCG64(11))
+    for h, w in [(64, 48), (37, 50), (224, 224)]:
+        x = g.integers(0, 256, size=(1, h, w, 3), dtype=np.uint8)
+        t = {"ShearX": A.shear_x_transform(0.27, False), "ShearY": A.shear_y_transform(0.27, True),
+             "TranslateX": A.translate_x_transform(90.0, False), "TranslateY": A.translate_y_transform(9.0, True),
+             "Rotate": A.rotate_transform(27.0, False, h, w), "Rotate (negated)": A.rotate_transform(27.0, True, h, w)}[name]
+        t = np.asarray(t, dtype=np.float32).reshape(-1)
+        ours = A.projective_transform(x, t, 128)[0]
+        a0, a1, a2, b0, b1, b2 = (float(v) for v in t[:6])
+        mat, off = np.array([[b1, b0], [a1, a0]]), np.array([b2, a2])          # arrays are indexed [y, x]
+        ref = np.stack([ndimage.affine_transform(x[0, ..., c].astype(np.float64), mat, offset=off, order=0, mode="constant", cval=128.0)
+                        for c in range(3)], axis=-1).astype(np.uint8)
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+        ix, iy = (t[0] * xs + t[1] * ys) + t[2], (t[3] * xs + t[4] * ys) + t[5]
+        e = 1e-3      # scipy works in float64: a coordinate that is exactly W - 1 in fp32 may sit a hair outside there
+        band = ((ix < e) & (ix > -0.5)) | ((ix > w - 1 - e) & (ix < w - 0.5)) | ((iy < e) & (iy > -0.5)) | ((iy > h - 1 - e) & (iy < h - 0.5))
+        tie = (np.abs(ix - np.floor(ix) - 0.5) < 1e-4) | (np.abs(iy - np.floor(iy) - 0.5) < 1e-4)      # exact .5: rounding conventions differ
+        diff = (ours != ref).any(-1)
+        assert not (diff & ~band & ~tie).any(), "%s at %dx%d: %d pixels differ away from the border band" % (name, h, w, int((diff & ~band & ~tie).sum()))
+        assert (~band).mean() > 0.9
+
+
+def test_resize_equals_torch_interpolate():
+    """tf.image.resize (TF2: half-pixel centres, no antialiasing) as restated by the oracle against torch's interpolate with the same
+    convention (`align_corners=False`, `antialias=False`; `nearest-exact`): nearest identical, bilinear to fp32 rounding (the two
+    evaluate the same two lerps in a different association)."""
+    g = np.random.Generator(np.random.PCG64(2))
+    x = g.integers(0, 256, size=(2, 37, 50, 3), dtype=np.uint8)
+    t = torch.from_numpy(x).permute(0, 3, 1, 2).float()
+    for oh, ow in [(64, 64), (20, 31), (74, 100), (224, 224)]:
+        ref = torch.nn.functional.interpolate(t, size=(oh, ow), mode="bilinear", align_corners=False, antialias=False).permute(0, 2, 3, 1).numpy()
+        assert float(np.abs(A.resize(x, oh, ow, "bilinear").astype(np.float64) - ref).max()) < 5e-4
+        refn = torch.nn.functional.interpolate(t, size=(oh, ow), mode="nearest-exact").permute(0, 2, 3, 1).numpy()
+        assert np.array_equal(A.resize(x, oh, ow, "nearest").astype(np.float32), refn)
