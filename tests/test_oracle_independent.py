@@ -155,3 +155,44 @@ def test_resize_equals_torch_interpolate():
         assert float(np.abs(A.resize(x, oh, ow, "bilinear").astype(np.float64) - ref).max()) < 5e-4
         refn = torch.nn.functional.interpolate(t, size=(oh, ow), mode="nearest-exact").permute(0, 2, 3, 1).numpy()
         assert np.array_equal(A.resize(x, oh, ow, "nearest").astype(np.float32), refn)
+
+
+def test_encoder_layer_equals_torch_transformer_encoder_layer():
+    """The pre-norm block the ViT uses (layers/transformer.py:56-58: x += MHA(LN1 x); x += W2 gelu(W1 LN2 x)) against
+    torch.nn.TransformerEncoderLayer(norm_first=True, activation=gelu) - somebody else's implementation of the same block - under
+    the weight mapping chambers' einsum layouts imply (w_query [D, heads, hd] = W_q^T etc.)."""
+    d, heads, ff, b, t = 96, 3, 192, 2, 29
+    hd = d // heads
+    g = torch.Generator().manual_seed(9)
+    pre = "encoder/layer_0/"
+    p = {pre + "multi_head_attention/w_query": torch.randn(d, heads, hd, generator=g) * 0.1, pre + "multi_head_attention/b_query": torch.randn(heads, 1, hd, generator=g) * 0.1,
+         pre + "multi_head_attention/w_key": torch.randn(d, heads, hd, generator=g) * 0.1, pre + "multi_head_attention/b_key": torch.randn(heads, 1, hd, generator=g) * 0.1,
+         pre + "multi_head_attention/w_value": torch.randn(d, heads, hd, generator=g) * 0.1, pre + "multi_head_attention/b_value": torch.randn(heads, 1, hd, generator=g) * 0.1,
+         pre + "multi_head_attention/w_projection": torch.randn(heads, d, hd, generator=g) * 0.1, pre + "multi_head_attention/b_projection": torch.randn(1, d, generator=g) * 0.1,
+         pre + "norm1/gamma": 1 + torch.randn(d, generator=g) * 0.1, pre + "norm1/beta": torch.randn(d, generator=g) * 0.1,
+         pre + "norm2/gamma": 1 + torch.randn(d, generator=g) * 0.1, pre + "norm2/beta": torch.randn(d, generator=g) * 0.1,
+         pre + "dense1/kernel": torch.randn(d, ff, generator=g) * 0.1, pre + "dense1/bias": torch.randn(ff, generator=g) * 0.1,
+         pre + "dense2/kernel": torch.randn(ff, d, generator=g) * 0.1, pre + "dense2/bias": torch.randn(d, generator=g) * 0.1}
+    x = torch.randn(b, t, d, generator=g)
+    ours = vit_ref.encoder_layer(x, p, pre, {"dropout_rate": 0.0, "n_heads": heads, "norm_epsilon": 1e-6}, {}, 0, False)
+
+    layer = torch.nn.TransformerEncoderLayer(d, heads, dim_feedforward=ff, dropout=0.0, activation="gelu", layer_norm_eps=1e-6, batch_first=True,
+                                             norm_first=True)
+    m = pre + "multi_head_attention/"
+    with torch.no_grad():
+        wq, wk, wv = (p[m + n].reshape(d, d).t() for n in ("w_query", "w_key", "w_value"))
+        layer.self_attn.in_proj_weight.copy_(torch.cat([wq, wk, wv], dim=0))
+        layer.self_attn.in_proj_bias.copy_(torch.cat([p[m + n].reshape(d) for n in ("b_query", "b_key", "b_value")]))
+        layer.self_attn.out_proj.weight.copy_(p[m + "w_projection"].permute(1, 0, 2).reshape(d, d))
+        layer.self_attn.out_proj.bias.copy_(p[m + "b_projection"].reshape(d))
+        layer.linear1.weight.copy_(p[pre + "dense1/kernel"].t()); layer.linear1.bias.copy_(p[pre + "dense1/bias"])
+        layer.linear2.weight.copy_(p[pre + "dense2/kernel"].t()); layer.linear2.bias.copy_(p[pre + "dense2/bias"])
+        layer.norm1.weight.copy_(p[pre + "norm1/gamma"]); layer.norm1.bias.copy_(p[pre + "norm1/beta"])
+        layer.norm2.weight.copy_(p[pre + "norm2/gamma"]); layer.norm2.bias.copy_(p[pre + "norm2/beta"])
+    layer.train()          # the fused inference fast path is a third implementation; the plain module path is the one to compare
+    theirs = layer(x)
+    assert torch.allclose(ours, theirs.detach(), rtol=0, atol=3e-5), float((ours - theirs.detach()).abs().max())
+    # and the reference's default post-norm composition against norm_first=False
+    layer.norm_first = False
+    ours_post = vit_ref.encoder_layer_post_norm(x, p, pre, {"dropout_rate": 0.0, "n_heads": heads, "norm_epsilon": 1e-6}, {}, 0, False)
+    assert torch.allclose(ours_post, layer(x).detach(), rtol=0, atol=3e-5)
