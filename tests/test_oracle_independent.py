@@ -196,3 +196,60 @@ def test_encoder_layer_equals_torch_transformer_encoder_layer():
     layer.norm_first = False
     ours_post = vit_ref.encoder_layer_post_norm(x, p, pre, {"dropout_rate": 0.0, "n_heads": heads, "norm_epsilon": 1e-6}, {}, 0, False)
     assert torch.allclose(ours_post, layer(x).detach(), rtol=0, atol=3e-5)
+
+
+def test_vit_forward_equals_huggingface_vit():
+    """The whole ViT graph of the oracle (vision_transformer.py:235-283: patch conv, class token on the LEFT, learned positions,
+    pre-norm blocks, final LayerNorm, class-token pooling, `predictions` head) against transformers' ViTForImageClassification - an
+    independent, widely used implementation of the same architecture - with random weights mapped through the layouts of
+    test_units/manual_test_vit_weights.py (conv OIHW -> HWIO, Linear weight^T -> [D, heads, hd] einsum kernels)."""
+    tr = pytest.importorskip("transformers")
+    from chambers_amd.engine import ViTConfig
+    d, heads, layers, ff, patch, h, w, classes = 96, 3, 2, 192, 16, 64, 48, 10
+    hd = d // heads
+    cfg = tr.ViTConfig(hidden_size=d, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ff, hidden_act="gelu",
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-6, image_size=(h, w), patch_size=patch,
+                       num_channels=3, qkv_bias=True, num_labels=classes)
+    torch.manual_seed(0)
+    model = tr.ViTForImageClassification(cfg).eval()
+    with torch.no_grad():
+        for t in model.parameters():
+            t.copy_(torch.randn_like(t) * 0.1)
+    sd = model.state_dict()
+    layer_key = "vit.layers.%d." if "vit.layers.0.layernorm_before.weight" in sd else "vit.encoder.layer.%d."
+
+    def pick(prefix, *names):      # the attribute names of the attention / MLP sub-modules changed between transformers releases
+        for n in names:
+            if prefix + n + ".weight" in sd:
+                return sd[prefix + n + ".weight"], sd[prefix + n + ".bias"]
+        raise KeyError(prefix + "|".join(names))
+
+    p = {"patch_embeddings/embedding/kernel": sd["vit.embeddings.patch_embeddings.projection.weight"].permute(2, 3, 1, 0).contiguous(),
+         "patch_embeddings/embedding/bias": sd["vit.embeddings.patch_embeddings.projection.bias"],
+         "add_cls_token/embeddings": sd["vit.embeddings.cls_token"].reshape(1, d),
+         "pos_embedding/embeddings": sd["vit.embeddings.position_embeddings"].reshape(-1, d),
+         "encoder/norm/gamma": sd["vit.layernorm.weight"], "encoder/norm/beta": sd["vit.layernorm.bias"],
+         "predictions/kernel": sd["classifier.weight"].t(), "predictions/bias": sd["classifier.bias"]}
+    for i in range(layers):
+        s, pre = layer_key % i, "encoder/layer_%d/" % i
+        for nm, cands in (("query", ("attention.q_proj", "attention.attention.query")), ("key", ("attention.k_proj", "attention.attention.key")),
+                          ("value", ("attention.v_proj", "attention.attention.value"))):
+            wt, bs = pick(s, *cands)
+            p[pre + "multi_head_attention/w_" + nm] = wt.t().reshape(d, heads, hd)
+            p[pre + "multi_head_attention/b_" + nm] = bs.reshape(heads, 1, hd)
+        wt, bs = pick(s, "attention.o_proj", "attention.output.dense")
+        p[pre + "multi_head_attention/w_projection"] = wt.reshape(d, heads, hd).permute(1, 0, 2)
+        p[pre + "multi_head_attention/b_projection"] = bs.reshape(1, d)
+        p[pre + "norm1/gamma"], p[pre + "norm1/beta"] = sd[s + "layernorm_before.weight"], sd[s + "layernorm_before.bias"]
+        p[pre + "norm2/gamma"], p[pre + "norm2/beta"] = sd[s + "layernorm_after.weight"], sd[s + "layernorm_after.bias"]
+        wt, bs = pick(s, "mlp.fc1", "intermediate.dense")
+        p[pre + "dense1/kernel"], p[pre + "dense1/bias"] = wt.t(), bs
+        wt, bs = pick(s, "mlp.fc2", "output.dense")
+        p[pre + "dense2/kernel"], p[pre + "dense2/bias"] = wt.t(), bs
+    x = torch.randn(2, h, w, 3, generator=torch.Generator().manual_seed(1))
+    c = ViTConfig(patch_size=patch, patch_dim=d, n_encoder_layers=layers, n_heads=heads, ff_dim=ff, image_size=(h, w), classes=classes, dropout_rate=0.0)
+    ours = vit_ref.vit_forward(p, x, c.as_oracle_cfg(), keys=None)
+    with torch.no_grad():
+        theirs = model(pixel_values=x.permute(0, 3, 1, 2).contiguous()).logits
+    assert ours.shape == theirs.shape == (2, classes)
+    assert float((ours - theirs).abs().max()) < 2e-4 * float(theirs.abs().max()), float((ours - theirs).abs().max())
