@@ -198,25 +198,11 @@ def test_encoder_layer_equals_torch_transformer_encoder_layer():
     assert torch.allclose(ours_post, layer(x).detach(), rtol=0, atol=3e-5)
 
 
-def test_vit_forward_equals_huggingface_vit():
-    """The whole ViT graph of the oracle (vision_transformer.py:235-283: patch conv, class token on the LEFT, learned positions,
-    pre-norm blocks, final LayerNorm, class-token pooling, `predictions` head) against transformers' ViTForImageClassification - an
-    independent, widely used implementation of the same architecture - with random weights mapped through the layouts of
+def _hf_to_keras_named(sd, root, d, heads, layers):
+    """transformers ViT / DeiT state dict -> the Keras-named tensors the oracle takes, through the layouts of
     test_units/manual_test_vit_weights.py (conv OIHW -> HWIO, Linear weight^T -> [D, heads, hd] einsum kernels)."""
-    tr = pytest.importorskip("transformers")
-    from chambers_amd.engine import ViTConfig
-    d, heads, layers, ff, patch, h, w, classes = 96, 3, 2, 192, 16, 64, 48, 10
     hd = d // heads
-    cfg = tr.ViTConfig(hidden_size=d, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ff, hidden_act="gelu",
-                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-6, image_size=(h, w), patch_size=patch,
-                       num_channels=3, qkv_bias=True, num_labels=classes)
-    torch.manual_seed(0)
-    model = tr.ViTForImageClassification(cfg).eval()
-    with torch.no_grad():
-        for t in model.parameters():
-            t.copy_(torch.randn_like(t) * 0.1)
-    sd = model.state_dict()
-    layer_key = "vit.layers.%d." if "vit.layers.0.layernorm_before.weight" in sd else "vit.encoder.layer.%d."
+    layer_key = root + ".layers.%d." if root + ".layers.0.layernorm_before.weight" in sd else root + ".encoder.layer.%d."
 
     def pick(prefix, *names):      # the attribute names of the attention / MLP sub-modules changed between transformers releases
         for n in names:
@@ -224,12 +210,11 @@ def test_vit_forward_equals_huggingface_vit():
                 return sd[prefix + n + ".weight"], sd[prefix + n + ".bias"]
         raise KeyError(prefix + "|".join(names))
 
-    p = {"patch_embeddings/embedding/kernel": sd["vit.embeddings.patch_embeddings.projection.weight"].permute(2, 3, 1, 0).contiguous(),
-         "patch_embeddings/embedding/bias": sd["vit.embeddings.patch_embeddings.projection.bias"],
-         "add_cls_token/embeddings": sd["vit.embeddings.cls_token"].reshape(1, d),
-         "pos_embedding/embeddings": sd["vit.embeddings.position_embeddings"].reshape(-1, d),
-         "encoder/norm/gamma": sd["vit.layernorm.weight"], "encoder/norm/beta": sd["vit.layernorm.bias"],
-         "predictions/kernel": sd["classifier.weight"].t(), "predictions/bias": sd["classifier.bias"]}
+    p = {"patch_embeddings/embedding/kernel": sd[root + ".embeddings.patch_embeddings.projection.weight"].permute(2, 3, 1, 0).contiguous(),
+         "patch_embeddings/embedding/bias": sd[root + ".embeddings.patch_embeddings.projection.bias"],
+         "add_cls_token/embeddings": sd[root + ".embeddings.cls_token"].reshape(1, d),
+         "pos_embedding/embeddings": sd[root + ".embeddings.position_embeddings"].reshape(-1, d),
+         "encoder/norm/gamma": sd[root + ".layernorm.weight"], "encoder/norm/beta": sd[root + ".layernorm.bias"]}
     for i in range(layers):
         s, pre = layer_key % i, "encoder/layer_%d/" % i
         for nm, cands in (("query", ("attention.q_proj", "attention.attention.query")), ("key", ("attention.k_proj", "attention.attention.key")),
@@ -246,6 +231,32 @@ def test_vit_forward_equals_huggingface_vit():
         p[pre + "dense1/kernel"], p[pre + "dense1/bias"] = wt.t(), bs
         wt, bs = pick(s, "mlp.fc2", "output.dense")
         p[pre + "dense2/kernel"], p[pre + "dense2/bias"] = wt.t(), bs
+    return p
+
+
+def _randomized(model):
+    torch.manual_seed(0)
+    model.eval()
+    with torch.no_grad():
+        for t in model.parameters():
+            t.copy_(torch.randn_like(t) * 0.1)
+    return model
+
+
+def test_vit_forward_equals_huggingface_vit():
+    """The whole ViT graph of the oracle (vision_transformer.py:235-283: patch conv, class token on the LEFT, learned positions,
+    pre-norm blocks, final LayerNorm, class-token pooling, `predictions` head) against transformers' ViTForImageClassification - an
+    independent, widely used implementation of the same architecture - with random weights mapped by _hf_to_keras_named."""
+    tr = pytest.importorskip("transformers")
+    from chambers_amd.engine import ViTConfig
+    d, heads, layers, ff, patch, h, w, classes = 96, 3, 2, 192, 16, 64, 48, 10
+    cfg = tr.ViTConfig(hidden_size=d, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ff, hidden_act="gelu",
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-6, image_size=(h, w), patch_size=patch,
+                       num_channels=3, qkv_bias=True, num_labels=classes)
+    model = _randomized(tr.ViTForImageClassification(cfg))
+    sd = model.state_dict()
+    p = _hf_to_keras_named(sd, "vit", d, heads, layers)
+    p["predictions/kernel"], p["predictions/bias"] = sd["classifier.weight"].t(), sd["classifier.bias"]
     x = torch.randn(2, h, w, 3, generator=torch.Generator().manual_seed(1))
     c = ViTConfig(patch_size=patch, patch_dim=d, n_encoder_layers=layers, n_heads=heads, ff_dim=ff, image_size=(h, w), classes=classes, dropout_rate=0.0)
     ours = vit_ref.vit_forward(p, x, c.as_oracle_cfg(), keys=None)
@@ -253,3 +264,31 @@ def test_vit_forward_equals_huggingface_vit():
         theirs = model(pixel_values=x.permute(0, 3, 1, 2).contiguous()).logits
     assert ours.shape == theirs.shape == (2, classes)
     assert float((ours - theirs).abs().max()) < 2e-4 * float(theirs.abs().max()), float((ours - theirs).abs().max())
+
+
+def test_distilled_vit_forward_equals_huggingface_deit():
+    """DistilledVisionTransformer (vision_transformer.py:295-400: distillation token concatenated first, class token on its left,
+    so the sequence is [cls, dist, patches]; heads `predictions` on row 0 and `predictions_dist` on row 1; their average when
+    return_dist_token=False) against transformers' DeiTForImageClassificationWithTeacher."""
+    tr = pytest.importorskip("transformers")
+    from chambers_amd.engine import ViTConfig
+    d, heads, layers, ff, patch, size, classes = 96, 3, 2, 192, 16, 64, 10
+    cfg = tr.DeiTConfig(hidden_size=d, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ff, hidden_act="gelu",
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-6, image_size=size, patch_size=patch,
+                        num_channels=3, qkv_bias=True, num_labels=classes)
+    model = _randomized(tr.DeiTForImageClassificationWithTeacher(cfg))
+    sd = model.state_dict()
+    p = _hf_to_keras_named(sd, "deit", d, heads, layers)
+    p["add_dist_token/embeddings"] = sd["deit.embeddings.distillation_token"].reshape(1, d)
+    p["predictions/kernel"], p["predictions/bias"] = sd["cls_classifier.weight"].t(), sd["cls_classifier.bias"]
+    p["predictions_dist/kernel"], p["predictions_dist/bias"] = sd["distillation_classifier.weight"].t(), sd["distillation_classifier.bias"]
+    x = torch.randn(2, size, size, 3, generator=torch.Generator().manual_seed(2))
+    c = ViTConfig(patch_size=patch, patch_dim=d, n_encoder_layers=layers, n_heads=heads, ff_dim=ff, image_size=(size, size), classes=classes,
+                  dropout_rate=0.0, distilled=True)
+    ours_cls, ours_dist = vit_ref.vit_forward(p, x, dict(c.as_oracle_cfg(), return_dist_token=True), keys=None)
+    ours_avg = vit_ref.vit_forward(p, x, dict(c.as_oracle_cfg(), return_dist_token=False), keys=None)
+    with torch.no_grad():
+        out = model(pixel_values=x.permute(0, 3, 1, 2).contiguous())
+    scale = float(out.logits.abs().max())
+    for a, b in ((ours_cls, out.cls_logits), (ours_dist, out.distillation_logits), (ours_avg, out.logits)):
+        assert float((a - b).abs().max()) < 2e-4 * scale
