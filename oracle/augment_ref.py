@@ -14,6 +14,9 @@ augmentation ops delegate their arithmetic to tensorflow==2.6.0 (pinned,
 requirements.txt:2) and tensorflow-addons (unpinned, requirements.txt:3), whose
 sources are not under /root/reference; their published algorithms are restated
 below and each such function says so ("upstream restated").
+Independent anchors (not the reference): tests/test_oracle_independent.py holds this file against Pillow - the implementation the
+AutoAugment ops were defined through - bit for bit for Invert, Posterize, Solarize, Equalize, AutoContrast and Brightness, within
+one grey level for Color and Sharpness, and against scipy.ndimage / torch for the warps and the resizes.
 
 Every random decision (sign flips, chance draws, op choice, cutout centres) is an
 explicit argument: the reference draws them from TF's stateful global RNG

@@ -18,6 +18,8 @@ Dropout, Adam) whose published algorithms are restated below.  `timm_block`
 restates the timm block the manual script compares against, and
 tests/test_oracle_vit.py checks this oracle equals it under the script's weight
 mapping (:27-76), which is the one equivalence the reference does state.
+Independent anchors (not the reference): tests/test_oracle_independent.py holds this file against torch's own GELU / LayerNorm /
+attention / TransformerEncoderLayer / AdamW and against HuggingFace transformers' ViT and DeiT models (whole forward, random weights).
 
 Gradients come from torch autograd over this forward.  Dropout masks are explicit
 (oracle/rng_ref.py defines them).  ``emulate_bf16=True`` rounds every GEMM operand
