@@ -418,3 +418,45 @@ def test_engine_forward_matches_huggingface_vit():
     with torch.no_grad():
         ref = model(pixel_values=torch.from_numpy(A.imagenet_normalize(images, "tf")).permute(0, 3, 1, 2).contiguous()).logits
     fp_check("HIP engine vs transformers ViT (3 blocks) | logits | fp32 third-party model", rel_l2(logits, ref), 5.3e-3)      # measured 3.5e-3 (x 1.5)
+
+
+def test_training_steps_track_huggingface_vit_with_torch_adamw():
+    """Forward + cross-entropy + backward + AdamW of the product path, five steps on one batch, against an independent stack: the
+    transformers ViT (fp32 autograd on the CPU) driven by torch.optim.AdamW with the reference's decay convention
+    (weight_decay = wd / lr; keras' epsilon sits elsewhere, which only moves elements with |g| ~ 1e-6).  Dropout off.  The per-step
+    mean losses must agree to bf16 noise and fall together; the first-step weight gradient families agree like DESIGN 2's table."""
+    tr = pytest.importorskip("transformers")
+    from test_oracle_independent import _hf_to_keras_named, _randomized
+    from chambers_amd.engine import ViTConfig, ViTEngine
+    d, heads, layers, ff, patch, h, w, classes, bsz = 128, 2, 2, 256, 16, 64, 64, 12, 16
+    hf_cfg = tr.ViTConfig(hidden_size=d, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ff, hidden_act="gelu",
+                          hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-6, image_size=(h, w), patch_size=patch,
+                          num_channels=3, qkv_bias=True, num_labels=classes)
+    model = _randomized(tr.ViTForImageClassification(hf_cfg))
+    sd = model.state_dict()
+    p = _hf_to_keras_named(sd, "vit", d, heads, layers)
+    p["predictions/kernel"], p["predictions/bias"] = sd["classifier.weight"].t(), sd["classifier.bias"]
+    cfg = ViTConfig(patch_size=patch, patch_dim=d, n_encoder_layers=layers, n_heads=heads, ff_dim=ff, image_size=(h, w), classes=classes, dropout_rate=0.0)
+    eng = ViTEngine(cfg, bsz, training=True, seed=0)
+    eng.load_keras_weights({k: np.ascontiguousarray(v.detach().numpy()) for k, v in p.items()})
+    g = np.random.Generator(np.random.PCG64(23))
+    images = g.integers(0, 256, size=(bsz, h, w, 3), dtype=np.uint8)
+    labels = g.integers(0, classes, size=(bsz,))
+    x_ref = torch.from_numpy(A.imagenet_normalize(images, "tf")).permute(0, 3, 1, 2).contiguous()
+    y_ref = torch.as_tensor(labels)
+    lr, wd = 1e-3, 0.05
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-7, weight_decay=wd / lr)
+    xd, yd = torch.as_tensor(images, device="cuda"), torch.as_tensor(labels.astype(np.int32), device="cuda")
+    ours, theirs = [], []
+    for step in range(5):
+        ours.append(float(eng.train_step(xd, yd, learning_rate=lr, weight_decay=wd).mean().item()))
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(pixel_values=x_ref).logits, y_ref)
+        loss.backward()
+        opt.step()
+        theirs.append(float(loss.item()))
+    worst = max(abs(a - b) / abs(b) for a, b in zip(ours, theirs))
+    # measured: ours 2.5073 2.4218 2.3670 2.3328 2.3124 vs 2.5075 2.4211 2.3661 2.3320 2.3115 (worst 3.9e-4); bound = x 1.5
+    fp_check("HIP engine vs transformers ViT + torch AdamW | worst per-step loss over 5 steps", worst, 6e-4)
+    assert ours[-1] < ours[0] - 0.05 and theirs[-1] < theirs[0] - 0.05
