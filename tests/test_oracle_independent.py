@@ -292,3 +292,28 @@ def test_distilled_vit_forward_equals_huggingface_deit():
     scale = float(out.logits.abs().max())
     for a, b in ((ours_cls, out.cls_logits), (ours_dist, out.distillation_logits), (ours_avg, out.logits)):
         assert float((a - b).abs().max()) < 2e-4 * scale
+
+
+@pytest.mark.parametrize("negate", [False, True])
+def test_rotate_direction_and_centre_equal_scipy_rotate(negate):
+    """tfa.image.rotate: counter-clockwise for a positive angle, about the centre ((W-1)/2, (H-1)/2) - the oracle's matrix
+    (augment_ref.rotate_transform, "upstream restated") against scipy.ndimage.rotate, which builds its own matrix from the angle:
+    Rotate(27 deg) is scipy's +27 deg and the negated draw is -27 deg, identical away from the half-pixel border band."""
+    ndimage = pytest.importorskip("scipy.ndimage")
+    g = np.random.Generator(np.random.PCG64(3))
+    for h, w in [(64, 48), (51, 51), (224, 224)]:
+        x = g.integers(0, 256, size=(1, h, w, 3), dtype=np.uint8)
+        t = np.asarray(A.rotate_transform(27.0, negate, h, w), dtype=np.float32).reshape(-1)
+        ours = A.projective_transform(x, t, 128)[0]
+        ref = ndimage.rotate(x[0].astype(np.float64), -27.0 if negate else 27.0, axes=(1, 0), reshape=False, order=0, mode="constant",
+                             cval=128.0).astype(np.uint8)
+        wrong = ndimage.rotate(x[0].astype(np.float64), 27.0 if negate else -27.0, axes=(1, 0), reshape=False, order=0, mode="constant",
+                               cval=128.0).astype(np.uint8)
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+        ix, iy = (t[0] * xs + t[1] * ys) + t[2], (t[3] * xs + t[4] * ys) + t[5]
+        e = 1e-3
+        band = ((ix < e) & (ix > -0.5)) | ((ix > w - 1 - e) & (ix < w - 0.5)) | ((iy < e) & (iy > -0.5)) | ((iy > h - 1 - e) & (iy < h - 0.5))
+        tie = (np.abs(ix - np.floor(ix) - 0.5) < 1e-4) | (np.abs(iy - np.floor(iy) - 0.5) < 1e-4)
+        diff = (ours != ref).any(-1)
+        assert not (diff & ~band & ~tie).any(), (h, w, int((diff & ~band & ~tie).sum()))
+        assert (ours != wrong).any(-1).mean() > 0.5          # the other direction is a different image
