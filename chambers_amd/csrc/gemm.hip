@@ -55,6 +55,34 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     return start + idx;
 }
 
+#ifdef CHB_CLOCK_STAMPS
+// Diagnostic build only (tools/gemm_clock.py through tools/ab_build.sh -DCHB_CLOCK_STAMPS): wave 0 of every workgroup stamps the
+// shader clock counter and the 100 MHz reference counter at kernel entry and exit into a buffer nothing else reads - the clock the
+// chip held over the launch is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back 6).
+__device__ unsigned long long g_clock_stamps[1024][4];
+__device__ __forceinline__ void clock_stamp(int which) {
+    if (threadIdx.x == 0) {
+        g_clock_stamps[blockIdx.x & 1023][which] = __builtin_amdgcn_s_memtime();
+        g_clock_stamps[blockIdx.x & 1023][which + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+#define CLOCK_STAMP(w) clock_stamp(w)
+#else
+#define CLOCK_STAMP(w)
+#endif
+#ifdef CHB_PHASE_STAMPS
+// Second diagnostic build (tools/gemm_phases.py): every wave reads the cycle counter at seven points of gemm_nt256_kernel's K-step
+// and sums the segments; waves 0 and 5 of each workgroup leave their sums in a buffer of their own.  Costs ~10 % of the loop.
+__device__ unsigned int g_phase_stamps[1024][2][10];
+#define PHASE_DECL unsigned int ph_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_prev = __builtin_amdgcn_s_memtime();
+#define PHASE(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_sum[i] += (unsigned int)(t_ - ph_prev); ph_prev = t_; }
+#define PHASE_FLUSH if (lane == 0 && (wave == 0 || wave == 5)) { for (int q_ = 0; q_ < 10; ++q_) g_phase_stamps[blockIdx.x & 1023][wave == 5][q_] = ph_sum[q_]; }
+#else
+#define PHASE_DECL
+#define PHASE(i)
+#define PHASE_FLUSH
+#endif
+
 __device__ __forceinline__ void glds16(const bf16_t* src, bf16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
@@ -236,15 +264,31 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmParams p) {
 // chunks of 4 columns), so that EVERY global access of the epilogue (residual / saved pre-activation
 // loads, output and aux stores) is 4 rows x 128..256 contiguous bytes per wave-instruction instead of
 // 16 rows x 32 bytes.  The scratch is XOR-swizzled (16-byte chunk ^ row) - conflict-free both ways.
-template <int EPI, int OUT, bool GUARD, int A0, int A1>
+// WIDE (bf16 outputs whose rows are 16-byte aligned): a lane owns EIGHT consecutive columns (8 lanes per row, 8 rows per
+// wave-instruction) so that bf16 rows and the saved gelu' rows also move as 16 bytes per lane - the store tail is bound by the
+// number of store instructions, not by their bytes (cdna_hip_programming.md T21): 16 instead of 32 per wave and output tile.
+template <int EPI, int OUT, bool GUARD, int A0, int A1, bool WIDE = false>
 __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stage, int m_base, int n_base, float4_t (&acc)[8][4],
                                                 int lane) {
+    constexpr int CW = (WIDE && OUT == CHB_OUT_BF16) ? 8 : 4;   // columns per lane
+    constexpr int NQ = CW / 4;                                   // 16-byte scratch chunks per lane and row
+    constexpr int LPR = 64 / CW;                                 // lanes per row: 16 | 8
+    constexpr int RPI = 64 / LPR;                                // rows per wave-instruction: 4 | 8
+    constexpr int NK = 16 / RPI;                                 // instructions per 16-row MFMA tile row: 4 | 2
     const int g = lane >> 4, i = lane & 15;
-    const int cr = lane >> 4, c4 = lane & 15;
-    const int col = n_base + c4 * 4;
+    const int cr = lane / LPR, cx = lane % LPR;
+    const int col = n_base + cx * CW;
     const bool colok = !GUARD || col < p.N;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && colok) bias = *reinterpret_cast<const float4*>(p.bias + col);
+    float bias[CW];
+#pragma unroll
+    for (int e = 0; e < CW; ++e) bias[e] = 0.f;
+    if (p.bias && colok) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col + 4 * q);
+            bias[4 * q] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
+        }
+    }
     // lane-constant pieces of every address (the per-(a,k) part is a compile-time row count times a uniform stride)
     constexpr int ESZ = (OUT == CHB_OUT_F32) ? 4 : 2;
     const int64_t row0 = (int64_t)m_base + cr;
@@ -254,32 +298,52 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
     const int64_t rstep = p.ld_resid * 4;
     char* abase = (EPI == CHB_EPI_GELU || EPI == CHB_EPI_DGELU) ? reinterpret_cast<char*>(p.aux) + (row0 * p.ld_aux + col) * 2 : nullptr;
     const int64_t astep = p.ld_aux * 2;
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    float csum[CW];
+#pragma unroll
+    for (int e = 0; e < CW; ++e) csum[e] = 0.f;
     float* wr[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) wr[b] = stage + i * 64 + (((4 * b + g) ^ i) << 2);
-    const float* rd[4];
+    // read-back: row RPI k + cr, scratch chunks NQ cx + q.  WIDE: a 16-lane group reads rows 2j (even chunks ^ row = one parity)
+    // and 2j + 1 (the other parity) - 16 different chunks, conflict-free like the 4-column form.
+    const float* rd[NK][NQ];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rd[k] = stage + (4 * k + cr) * 64 + ((c4 ^ (4 * k + cr)) << 2);
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rd[k][q] = stage + (RPI * k + cr) * 64 + (((NQ * cx + q) ^ (RPI * k + cr)) << 2);
     // The epilogue's own global loads (residual / saved gelu' / positional rows) run DEPTH tile rows ahead: the loads of row
     // a + DEPTH are issued before row a crosses LDS.  Measured (tools/ab_build.sh, depths 0-5 A/B in one session): no depth
     // changes the wall time of any shape by more than run-to-run noise (+-2 %) - the epilogue is not waiting on these loads.
     constexpr bool HAS_IN = (EPI == CHB_EPI_PATCH || EPI == CHB_EPI_RESID || EPI == CHB_EPI_DGELU);
     constexpr int DEPTH = (EPI == CHB_EPI_RESID) ? EPI_DEPTH_RESID : (EPI == CHB_EPI_DGELU) ? EPI_DEPTH_DGELU : 1;   // rows in flight ahead
-    float4 r4buf[DEPTH + 1][4];
-    uint2 a2buf[DEPTH + 1][4];
-    auto load_inputs = [&](int a, float4 (&r4)[4], uint2 (&a2)[4]) {
+    float4 r4buf[DEPTH + 1][NK][NQ];
+    uint32_t a2buf[DEPTH + 1][NK][CW / 2];
+    auto load_inputs = [&](int a, float4 (&r4)[NK][NQ], uint32_t (&a2)[NK][CW / 2]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int rr = a * 16 + 4 * k;
+        for (int k = 0; k < NK; ++k) {
+            const int rr = a * 16 + RPI * k;
             const int row = m_base + rr + cr;
             const bool okk = colok && (!GUARD || row < p.M);
             if (EPI == CHB_EPI_PATCH) {
                 const int bi = row / p.period, pp = row - bi * p.period;
-                if (okk) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.n_special + pp) * p.ld_resid + col);
+                if (okk) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) r4[k][q] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.n_special + pp) * p.ld_resid + col + 4 * q);
+                }
             }
-            if (EPI == CHB_EPI_RESID && okk) r4[k] = *reinterpret_cast<const float4*>(rbase + rr * rstep);
-            if (EPI == CHB_EPI_DGELU && okk) a2[k] = *reinterpret_cast<const uint2*>(abase + rr * astep);
+            if (EPI == CHB_EPI_RESID && okk) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) r4[k][q] = *reinterpret_cast<const float4*>(rbase + rr * rstep + 16 * q);
+            }
+            if (EPI == CHB_EPI_DGELU && okk) {
+                if (CW == 8) {
+                    const uint4 t4 = *reinterpret_cast<const uint4*>(abase + rr * astep);
+                    a2[k][0] = t4.x; a2[k][1] = t4.y; a2[k][CW / 2 - 2] = t4.z; a2[k][CW / 2 - 1] = t4.w;
+                } else {
+                    const uint2 t2 = *reinterpret_cast<const uint2*>(abase + rr * astep);
+                    a2[k][0] = t2.x; a2[k][1] = t2.y;
+                }
+            }
         }
     };
     if (HAS_IN) {
@@ -289,14 +353,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
     }
 #pragma unroll
     for (int a = A0; a < A1; ++a) {
-        float4 (&r4)[4] = r4buf[(a - A0) % (DEPTH + 1)];
-        uint2 (&a2)[4] = a2buf[(a - A0) % (DEPTH + 1)];
+        float4 (&r4)[NK][NQ] = r4buf[(a - A0) % (DEPTH + 1)];
+        uint32_t (&a2)[NK][CW / 2] = a2buf[(a - A0) % (DEPTH + 1)];
         if (HAS_IN && a + DEPTH < A1) load_inputs(a + DEPTH, r4buf[(a + DEPTH - A0) % (DEPTH + 1)], a2buf[(a + DEPTH - A0) % (DEPTH + 1)]);
-        int64_t orow[4];
-        bool ok[4];
+        int64_t orow[NK];
+        bool ok[NK];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int rr = a * 16 + 4 * k;                      // compile-time row offset inside the wave's 128 rows
+        for (int k = 0; k < NK; ++k) {
+            const int rr = a * 16 + RPI * k;                    // compile-time row offset inside the wave's 128 rows
             const int row = m_base + rr + cr;
             orow[k] = row;
             ok[k] = colok && (!GUARD || row < p.M);
@@ -307,70 +371,85 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) *reinterpret_cast<float4_t*>(wr[b]) = acc[a][b];
-        float4_t t[4];
+        float4_t t[NK][NQ];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const float4_t*>(rd[k]);
+        for (int k = 0; k < NK; ++k)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int rr = a * 16 + 4 * k;
-            float v[4] = {t[k][0] + bias.x, t[k][1] + bias.y, t[k][2] + bias.z, t[k][3] + bias.w};
+            for (int q = 0; q < NQ; ++q) t[k][q] = *reinterpret_cast<const float4_t*>(rd[k][q]);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int rr = a * 16 + RPI * k;
+            float v[CW];
+#pragma unroll
+            for (int e = 0; e < CW; ++e) v[e] = t[k][e >> 2][e & 3] + bias[e];
             if (EPI == CHB_EPI_GELU) {
-                float d[4];
+                uint32_t der[CW / 2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], d[e]);
-                uint2 der;
-                der.x = pack_bf16x2(d[0], d[1]);
-                der.y = pack_bf16x2(d[2], d[3]);
-                if (ok[k]) *reinterpret_cast<uint2*>(abase + rr * astep) = der;
+                for (int q = 0; q < NQ; ++q) {
+                    float d[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gelu_both(v[4 * q + e], v[4 * q + e], d[e]);
+                    der[2 * q] = pack_bf16x2(d[0], d[1]);
+                    der[2 * q + 1] = pack_bf16x2(d[2], d[3]);
+                    // keep the erf polynomial of one 4-element group from being interleaved with the next: the wider schedule
+                    // needs more than the 256 registers a wave has here and spills (measured: 0.82 -> 0.73 ms on the fc1 GEMM)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ok[k]) {
+                    if (CW == 8) *reinterpret_cast<uint4*>(abase + rr * astep) = make_uint4(der[0], der[1], der[CW / 2 - 2], der[CW / 2 - 1]);
+                    else *reinterpret_cast<uint2*>(abase + rr * astep) = make_uint2(der[0], der[1]);
+                }
             } else if (EPI == CHB_EPI_DGELU) {
-                v[0] *= bf16_to_f32((bf16_t)(a2[k].x & 0xffff));
-                v[1] *= bf16_to_f32((bf16_t)(a2[k].x >> 16));
-                v[2] *= bf16_to_f32((bf16_t)(a2[k].y & 0xffff));
-                v[3] *= bf16_to_f32((bf16_t)(a2[k].y >> 16));
+#pragma unroll
+                for (int e = 0; e < CW; e += 2) {
+                    v[e] *= bf16_to_f32((bf16_t)(a2[k][e >> 1] & 0xffff));
+                    v[e + 1] *= bf16_to_f32((bf16_t)(a2[k][e >> 1] >> 16));
+                }
             } else if (EPI == CHB_EPI_RESID || EPI == CHB_EPI_PATCH) {
                 if (EPI == CHB_EPI_PATCH) {
-                    v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { v[4 * q] += r4[k][q].x; v[4 * q + 1] += r4[k][q].y; v[4 * q + 2] += r4[k][q].z; v[4 * q + 3] += r4[k][q].w; }
                 }
                 if (p.drop_thr) {
                     const uint64_t e0 = (uint64_t)orow[k] * (uint64_t)p.N + (uint64_t)col;
-                    bool k0, k1, k2, k3;
-                    chb_keep2((uint32_t)(e0 >> 1), p.drop_key, p.drop_thr, k0, k1);
-                    chb_keep2((uint32_t)(e0 >> 1) + 1u, p.drop_key, p.drop_thr, k2, k3);
-                    v[0] = k0 ? v[0] * p.drop_scale : 0.0f;
-                    v[1] = k1 ? v[1] * p.drop_scale : 0.0f;
-                    v[2] = k2 ? v[2] * p.drop_scale : 0.0f;
-                    v[3] = k3 ? v[3] * p.drop_scale : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < CW; e += 2) {
+                        bool k0, k1;
+                        chb_keep2((uint32_t)(e0 >> 1) + (uint32_t)(e >> 1), p.drop_key, p.drop_thr, k0, k1);
+                        v[e] = k0 ? v[e] * p.drop_scale : 0.0f;
+                        v[e + 1] = k1 ? v[e + 1] * p.drop_scale : 0.0f;
+                    }
                 }
                 if (EPI == CHB_EPI_RESID) {
-                    v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { v[4 * q] += r4[k][q].x; v[4 * q + 1] += r4[k][q].y; v[4 * q + 2] += r4[k][q].z; v[4 * q + 3] += r4[k][q].w; }
                 }
             }
             char* dst = (EPI == CHB_EPI_PATCH) ? reinterpret_cast<char*>(p.C) + (orow[k] * p.ldc + col) * ESZ : cbase + rr * cstep;
             if (ok[k]) {
                 if (OUT == CHB_OUT_F32) {
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (CW == 8) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[CW - 4], v[CW - 3]),
+                                                               pack_bf16x2(v[CW - 2], v[CW - 1]));
                 } else {
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = o;
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
-                csum[0] += v[0]; csum[1] += v[1]; csum[2] += v[2]; csum[3] += v[3];
+#pragma unroll
+                for (int e = 0; e < CW; ++e) csum[e] += v[e];
             }
-            // keep the erf polynomial of one 4-element group from being interleaved with the next three: the wider schedule
-            // needs more than the 256 registers a wave has here and spills (measured: 0.82 -> 0.73 ms on the fc1 GEMM)
-            if (EPI == CHB_EPI_GELU) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (p.colsum) {   // this wave's 128 rows x 64 columns: fold the 4 row-groups (lanes cr) and add once per column
+    if (p.colsum) {   // this wave's 128 rows x 64 columns: fold the row groups (lanes cr) and add once per column
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < CW; ++e) {
+            if (CW == 8) csum[e] += __shfl_xor(csum[e], 8, 64);
             csum[e] += __shfl_xor(csum[e], 16, 64);
             csum[e] += __shfl_xor(csum[e], 32, 64);
         }
         if (cr == 0 && colok) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(p.colsum + col + e, csum[e]);
+            for (int e = 0; e < CW; ++e) atomicAdd(p.colsum + col + e, csum[e]);
         }
     }
 }
@@ -498,6 +577,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     TileWalk w;
     tile_walk_init(w, p);
     if (w.slot >= w.cnt) return;
+    CLOCK_STAMP(0);
     // Tile queue (K >= 8 K-tiles): a workgroup's first tile is its static one, every later tile is the next ticket of its XCD's
     // counter.  A workgroup that starts late (its CU was held by another stream's kernel - a collective) then simply draws fewer
     // tickets: the launch loses that CU's share of the time it was away, not a whole static tile share at the end.
@@ -553,7 +633,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     const int a_off0 = i * 64 + (((0 + g) ^ sw) << 3), a_off1 = i * 64 + (((4 + g) ^ sw) << 3);
     const int b_off0 = ((wn & 1) * 64 + i) * 64 + (((0 + g) ^ sw) << 3), b_off1 = ((wn & 1) * 64 + i) * 64 + (((4 + g) ^ sw) << 3);
 
+    PHASE_DECL
     for (int s = 0; cc.valid; ++s) {
+        PHASE(0)       // cursor bookkeeping (and, once per tile, the epilogue: counted apart below)
         bf16_t* ring = smem + (s & 1) * 4 * 8192;
         bf16_t* nring = smem + ((s + 1) & 1) * 4 * 8192;
         const bf16_t* As = ring + wm * 8192;
@@ -579,6 +661,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
             for (int ks = 0; ks < 2; ++ks) af[a][ks] = *reinterpret_cast<const bf16x8_t*>(As + (ks ? a_off1 : a_off0) + a * 16 * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        PHASE(1)       // A staging issue + 16 fragment reads + their wait
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -588,6 +671,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
                 for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[b][ks], af[a][ks], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        PHASE(2)       // 32 MFMAs issued
 
         // ---------------- phase 2: rows 64-127 (32 MFMAs).  No barrier separates the phases: the one below orders every read of
         // this ring (B and A rows 0-63 in phase 1, A rows 64-127 here) before the restaging that follows it.
@@ -596,10 +680,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[a][ks] = *reinterpret_cast<const bf16x8_t*>(As + (ks ? a_off1 : a_off0) + (64 + a * 16) * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PHASE(3)       // 8 fragment reads + their wait
         // all of step s+1 (A issued in phase 1 of this step, B after the previous step's barrier) has landed when the barrier opens
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PHASE(4)       // vmcnt(0)
         __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A and B half-tiles; step s+1 has landed
         __builtin_amdgcn_sched_barrier(0);
+        PHASE(5)       // barrier
         if (w.dyn) {
             // The ticket is drawn right behind this step's vmcnt(0): its round trip has a whole K-step before the next vmcnt(0)
             // has to cover it.  (Inline asm: hipcc's atomicAdd aggregates over the wave and reads the result back at once - an
@@ -642,20 +729,29 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
                 for (int b = 0; b < 4; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[b][ks], af[a][ks], acc[4 + a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        PHASE(6)       // B staging issue + 32 MFMAs issued
 
         cursor_next(ca, w);
         cursor_next(cb, w);
         // ---------------- end of an output tile: epilogue (later steps' loads keep flying)
         if (last_k) {
-            if (FAST || interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            PHASE(7)
+            if (FAST) epilogue_staged<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            else if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            PHASE(8)   // epilogue
+#ifdef CHB_PHASE_STAMPS
+            ph_sum[9] += 1;
+#endif
         }
         cursor_next(cc, w);
     }
+    PHASE_FLUSH
+    CLOCK_STAMP(2);
 }
 
 
@@ -805,7 +901,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256pp_kernel(GemmParams p) {
         CHB_PP_SYNC_MFMA(4, 0, 1, (T & 1) * 4 + 1)
 
         if (last_k) {
-            epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + grp * 128, cc.n0 + wn * 64, acc, lane);
+            epilogue_staged<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + grp * 128, cc.n0 + wn * 64, acc, lane);
             // leave only (at most) the epilogue's own memory operations outstanding: every staging element issued before it has landed
             constexpr int EPI_OPS = (EPI == CHB_EPI_NONE) ? 32 : 63;
             if (EPI_OPS == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -1520,7 +1616,7 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
         return CHB_OK;
     }
     if (algo == 4) {     // ping-pong schedule: full tiles and >= 4 K-tiles only
-        if ((p.M & 255) || (p.N & 255) || p.K < 4 * BK) algo = 2;
+        if ((p.M & 255) || (p.N & 255) || p.K < 4 * BK || (p.ldc & 7) || (p.aux && (p.ld_aux & 7))) algo = 2;
     }
     if (algo == 4) {
         p.tiles_m = p.M / 256;
@@ -1538,7 +1634,8 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
         int grid = num_cus() & ~7;
         if (grid < 8) grid = 8;
         const dim3 g(grid), block(512);
-        const bool fast = !(p.M & 255) && !(p.N & 255);       // every tile full: the clamped staging and the guarded epilogue are compiled out
+        // every tile full: the clamped staging and the guarded epilogue are compiled out; bf16 rows leave as 16-byte stores (WIDE)
+        const bool fast = !(p.M & 255) && !(p.N & 255) && (out_dtype == CHB_OUT_F32 || (!(p.ldc & 7) && !(p.aux && (p.ld_aux & 7))));
         if (out_dtype == CHB_OUT_F32) {
             if (fast) hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_F32, true>), g, block, 0, s, p);
             else hipLaunchKernelGGL((gemm_nt256_kernel<EPI, CHB_OUT_F32, false>), g, block, 0, s, p);
@@ -1692,4 +1789,16 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
     return CHB_OK;
 }
 
+#ifdef CHB_PHASE_STAMPS
+int chb_debug_phase_stamps(unsigned int* host_out, int n_groups) {   // diagnostic build only
+    if (n_groups > 1024) n_groups = 1024;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_stamps), sizeof(unsigned int) * 20 * n_groups) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef CHB_CLOCK_STAMPS
+int chb_debug_clock_stamps(unsigned long long* host_out, int n_groups) {   // diagnostic build only, not part of the ABI
+    if (n_groups > 1024) n_groups = 1024;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_stamps), sizeof(unsigned long long) * 4 * n_groups) == hipSuccess ? 0 : -1;
+}
+#endif
 }  // extern "C"
