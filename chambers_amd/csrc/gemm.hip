@@ -26,7 +26,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 #define EPI_DEPTH_RESID 1
 #endif
 #ifndef EPI_DEPTH_DGELU
-#define EPI_DEPTH_DGELU 1
+#define EPI_DEPTH_DGELU 0
 #endif
 constexpr int TILE_ELEMS = 128 * 64;  // one operand tile, either orientation
 
@@ -520,6 +520,16 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ g, int64_t
     }
 }
 
+// one of the 16 instructions of a half-tile (8 rows), edge rows clamped
+__device__ __forceinline__ void stage_piece_clamped(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0,
+                                                    bf16_t* lds_half, int inst, int lane) {
+    const int r = inst * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int gr = row0 + r;
+    gr = gr < max_row ? gr : max_row - 1;
+    glds16(g + (int64_t)gr * ld + k0 + c * 8, lds_half + inst * 512);
+}
+
 // The same with the address split into a wave-uniform base (SALU: tile row, k offset) and two lane-constant 32-bit byte offsets
 // (row within the half-tile x leading dimension + swizzled chunk), for half-tiles that need no row clamp: one 64-bit add per
 // LDS-DMA instruction instead of a clamp, two 32-bit multiplies and a 64-bit multiply-add per lane.
@@ -753,6 +763,246 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     PHASE_FLUSH
     CLOCK_STAMP(2);
 }
+
+
+// ---- NT, persistent 256x256 tiles, fragment reads software-pipelined under the MFMAs, staging spread over the K-step ----------
+// Same geometry, ring and epilogue as gemm_nt256_kernel.  What tools/gemm_phases.py and the ablation builds (CHB_ABL_*) showed
+// on the lockstep kernel: with the staging left out it runs 1.4x faster, with the fragment reads left out 1.07x - the cost is
+// the LDS-DMA, and it is paid twice: (a) the 64 one-KiB instructions of a K-step all leave in one burst behind the barrier, the
+// CU's address unit takes them one per ~16 cycles, and a wave queued there issues no MFMA; (b) the A operand (activations, new
+// to the chip) has half a K-step to land.  This kernel therefore
+//  * cuts the K-step into FOUR quarters of 16 MFMAs, ordered so that all of B and rows 0-63 of A are read out after the second:
+//      Q0  read bK1 = B(k-half 1), aY = A(rows 0-63, k-half 1)        | acc[0..3] += bK0 x aX
+//      Q1  read aX = A(rows 64-127, k-half 0) | lgkmcnt(4) | BARRIER 1 | acc[0..3] += bK1 x aY     + 3 pieces of step s+2
+//      Q2  read aY = A(rows 64-127, k-half 1)                          | acc[4..7] += bK0 x aX     + 3 pieces
+//          lgkmcnt(0) | counted vmcnt: step s+1 has landed | BARRIER 2
+//      Q3  read bK0, aX of step s+1 (other ring)                       | acc[4..7] += bK1 x aY     + 2 pieces (A rows 64-127)
+//    every quarter issues the NEXT quarter's fragment reads first (inline asm, hand-counted lgkmcnt - see below), so no ds_read
+//    burst stands in front of an MFMA block; the same 64 fragment registers as the lockstep kernel, the same K order per
+//    accumulator (bit-identical output);
+//  * frees 48 of the ring's 64 KiB per step at barrier 1: six of a wave's eight pieces go out over Q1-Q2, one in front of a group
+//    of four MFMAs, with more than a whole K-step to land; the step-end wait leaves exactly those six in flight (vmcnt(6));
+//  * keeps wave-uniform byte pointers of the two staging streams, so a piece is an LDS-offset move, one 64-bit add and the
+//    LDS-DMA instead of a 64-bit multiply-add chain.
+// Measured steps on the way (tools/gemm_ab.py, bit-equal each): reads pipelined only -2..-4 % vs lockstep; + pointer streams and
+// pieces between MFMAs +1..+3 %; pieces split Q3 / next Q0 (later, not earlier) -2..-5 %; an L2 touch of A two or four steps
+// ahead -3..-5 %; staggering the two wave groups 0 %; barrier 1 with B early +3..+6 %.  On a tile's last K-step the Q3 read is
+// left out and done after the epilogue instead, so the epilogue keeps its registers.
+// Fragment reads of the pipelined kernel are inline asm with hand-counted waits.  hipcc cannot count them: an LDS-DMA
+// (global_load_lds) in flight is a "flat access that may touch LDS" to its wait-count pass, and while one is pending it turns every
+// lgkmcnt wait into lgkmcnt(0) - which here is always, by design.  The waits name the registers they make valid ("+v"), so no
+// use of a fragment can be scheduled above its wait.
+template <int OFF>
+__device__ __forceinline__ void ds_read128(bf16x8_t& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+#define FRAG4(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)LDS_PTR(p); }
+
+template <int EPI, int OUT, bool FAST>
+__global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * 8192 + 8 * 2048];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, i = lane & 15;
+
+    TileWalk w;
+    tile_walk_init(w, p);
+    if (w.slot >= w.cnt) return;
+    w.dyn = 0;
+
+    uint32_t offa[2], offb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        offa[j] = (uint32_t)(((int64_t)r * p.lda + c * 8) * 2);
+        offb[j] = (uint32_t)(((int64_t)r * p.ldb + c * 8) * 2);
+    }
+    Cursor cs, cc;                    // staging stream (two steps ahead of compute), compute
+    cursor_set(cc, w, 0);
+    cursor_set(cs, w, 0);
+    // Staging stream: wave-uniform byte pointers to (tile row / column 0, current K-tile) of A and B, moved by one K-tile per step
+    // and recomputed only when the stream enters a new output tile - a piece (one 1 KiB LDS-DMA instruction) then costs one
+    // 64-bit add instead of a 64-bit multiply-add chain (tools/gemm_phases.py + ablations: the 64 pieces of a K-step cost the
+    // lockstep kernel about as much wall time as a quarter of its MFMAs, half of it scalar address arithmetic in front of each).
+    const char* pa = nullptr;
+    const char* pb = nullptr;
+    const int64_t a_half = (int64_t)128 * p.lda * 2, b_half = (int64_t)128 * p.ldb * 2;
+    auto stream_set = [&]() {
+        pa = reinterpret_cast<const char*>(p.A + (int64_t)cs.m0 * p.lda + cs.kt * BK);
+        pb = reinterpret_cast<const char*>(p.B + (int64_t)cs.n0 * p.ldb + cs.kt * BK);
+    };
+    auto stream_next = [&]() {
+        cursor_next(cs, w);
+        if (cs.kt == 0) stream_set();
+        else { pa += BK * 2; pb += BK * 2; }
+    };
+    // piece e of a step: e = 0..3 -> B (half e >> 1, instruction e & 1), e = 4..7 -> A; instruction 0 of a half = its rows 0-63
+    auto piece = [&](int e, bf16_t* ring_) {
+        const int h = (e >> 1) & 1, j = e & 1;
+        if (e < 4) {
+            if (FAST || cs.n0 + h * 128 + 128 <= p.N) glds16(reinterpret_cast<const bf16_t*>(pb + h * b_half + offb[j]), ring_ + (2 + h) * 8192 + (j * 8 + wave) * 512);
+            else stage_piece_clamped(p.B, p.ldb, cs.n0 + h * 128, p.N, cs.kt * BK, ring_ + (2 + h) * 8192, j * 8 + wave, lane);
+        } else {
+#ifndef CHB_ABL_HALF
+            if (FAST || cs.m0 + h * 128 + 128 <= p.M) glds16(reinterpret_cast<const bf16_t*>(pa + h * a_half + offa[j]), ring_ + h * 8192 + (j * 8 + wave) * 512);
+            else stage_piece_clamped(p.A, p.lda, cs.m0 + h * 128, p.M, cs.kt * BK, ring_ + h * 8192, j * 8 + wave, lane);
+#endif
+        }
+    };
+    auto stage_step = [&](bf16_t* ring_) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) piece(e, ring_);
+    };
+    stream_set();
+    stage_step(smem);
+    stream_next();
+    if (cs.valid) stage_step(smem + 4 * 8192);
+    // ragged halves issue a different number of LDS-DMA instructions: only the full-tile build may count
+    if (FAST && cs.valid) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stream_next();
+    __builtin_amdgcn_s_barrier();
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int sw = (i >> 1) & 7;
+    const int a_off0 = i * 64 + (((0 + g) ^ sw) << 3), a_off1 = i * 64 + (((4 + g) ^ sw) << 3);
+    const int b_off0 = ((wn & 1) * 64 + i) * 64 + (((0 + g) ^ sw) << 3), b_off1 = ((wn & 1) * 64 + i) * 64 + (((4 + g) ^ sw) << 3);
+    bf16x8_t aX[4], aY[4], bK0[4], bK1[4];
+    // byte addresses of the four lane bases in ring 0 (A / B x k-half); fragment t of a set is +2 KiB t, rows 64-127 +8 KiB
+    const uint32_t a_adr0 = lds_addr(smem + wm * 8192 + a_off0), a_adr1 = lds_addr(smem + wm * 8192 + a_off1);
+    const uint32_t b_adr0 = lds_addr(smem + (2 + (wn >> 1)) * 8192 + b_off0), b_adr1 = lds_addr(smem + (2 + (wn >> 1)) * 8192 + b_off1);
+#ifdef CHB_ABL_NOREAD
+#define READ4(x, adr, base) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "v"(adr)); }
+#else
+#define READ4(x, adr, base) { ds_read128<(base)>(x[0], adr); ds_read128<(base) + 2048>(x[1], adr); ds_read128<(base) + 4096>(x[2], adr); ds_read128<(base) + 6144>(x[3], adr); }
+#endif
+    READ4(bK0, b_adr0, 0)
+    READ4(aX, a_adr0, 0)
+    constexpr int EPI_OPS = !FAST ? 0 : (EPI == CHB_EPI_NONE) ? 16 : (EPI == CHB_EPI_GELU || EPI == CHB_EPI_DGELU) ? 32 : 63;
+
+    PHASE_DECL
+    for (int s = 0; cc.valid; ++s) {
+        bf16_t* ring = smem + (s & 1) * 4 * 8192;
+        const uint32_t ro = (s & 1) * 65536, nro = 65536 - ro;          // ring byte offsets: this step's, the next step's
+        const uint32_t aA0 = a_adr0 + ro, aA1 = a_adr1 + ro, bA1 = b_adr1 + ro;
+        const uint32_t naA0 = a_adr0 + nro, nbA0 = b_adr0 + nro;
+        const bool last_k = cc.kt == w.ntk - 1;
+        const bool first_k = cc.kt == 0 && s > 0;
+        const bool interior = cc.m0 + 256 <= p.M && cc.n0 + 256 <= p.N;
+        float* stage = reinterpret_cast<float*>(smem + 2 * 4 * 8192) + wave * 1024;
+
+        // ---- Q0   (in flight on entry: bK0, aX = A rows 0-63 k-half 0: 8 reads)
+        READ4(bK1, bA1, 0)
+        READ4(aY, aA1, 0)
+        asm volatile("s_waitcnt lgkmcnt(8)" : FRAG4(bK0), FRAG4(aX));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bK0[b], aX[a], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Q1
+        READ4(aX, aA0, 8192)
+        asm volatile("s_waitcnt lgkmcnt(4)" : FRAG4(bK1), FRAG4(aY) : : "memory");
+        // barrier 1: every wave has read ALL of B and rows 0-63 of both A halves of this ring - those 48 KiB take step s+2 now,
+        // one piece in front of a group of four MFMAs, over Q1 and Q2
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool staging = cs.valid;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#ifndef CHB_ABL_NOSTAGE
+            if (staging && a < 3) piece(a == 2 ? 4 : a, ring);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bK1[b], aY[a], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- Q2
+        READ4(aY, aA1, 8192)
+        asm volatile("s_waitcnt lgkmcnt(4)" : FRAG4(aX));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#ifndef CHB_ABL_NOSTAGE
+            if (staging && a < 3) piece(a == 2 ? 6 : 2 + a, ring);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bK0[b], aX[a], acc[4 + a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- barrier 2: this ring is read out, step s+1 has landed.  The counter retires in issue order: what may stay in flight
+        // is what was issued AFTER the last LDS-DMA of step s+1 - this step's six early pieces and, behind a tile's epilogue, its
+        // loads and stores.  Ragged builds issue a varying number of instructions per piece and wait for everything.
+        asm volatile("s_waitcnt lgkmcnt(0)" : FRAG4(aY) : : "memory");
+        PHASE(1)       // Q3 of the previous step, bookkeeping, Q0, Q1, Q2 and the last reads' wait
+        {
+            const int young = !FAST ? 0 : (staging ? 6 : 0) + (first_k ? EPI_OPS : 0);
+            if (young >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            else if (young == 38) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+            else if (young == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (young == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else if (young == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PHASE(4)       // vmcnt
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PHASE(5)       // barrier
+        // ---- Q3
+        if (!last_k) {
+            READ4(bK0, nbA0, 0)
+            READ4(aX, naA0, 0)
+        }
+        // rows 64-127 of both A halves of step s+2
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#ifndef CHB_ABL_NOSTAGE
+            if (staging && a < 2) piece(5 + 2 * a, ring);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bK1[b], aY[a], acc[4 + a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (staging) stream_next();
+
+        if (last_k) {
+            PHASE(7)
+            if (FAST) epilogue_staged<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            else if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            // the next tile's first fragments (its step 0 landed before this step's barrier)
+            READ4(bK0, nbA0, 0)
+            READ4(aX, naA0, 0)
+            PHASE(8)   // epilogue
+#ifdef CHB_PHASE_STAMPS
+            ph_sum[9] += 1;
+#endif
+        }
+        cursor_next(cc, w);
+    }
+    PHASE_FLUSH
+}
+#undef READ4
 
 
 // ---- NT, persistent 256x256 tiles, two wave groups in anti-phase ("ping-pong") ----------------------------------------------
@@ -1589,14 +1839,18 @@ int num_cus() {
     return n;
 }
 
-// 0 = automatic, 1 = 128x128 tiles (one workgroup per tile), 2 = persistent 256x256 tiles, 3 = persistent 128x256 x 2 WG/CU
+// 0 = automatic, 1 = 128x128 tiles (one workgroup per tile), 2 = persistent 256x256 tiles (lockstep), 3 = persistent 128x256 x 2 WG/CU,
+// 4 = persistent 256x256 ping-pong, 5 = persistent 256x256 pipelined reads + spread staging (the automatic choice for large shapes)
 int gemm_algo_override() { return chb_option(CHB_OPT_GEMM_ALGO); }
 
 template <int EPI>
 int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
     int algo = gemm_algo_override();
-    if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? 2 : 1;
-    if (p.colsum && algo != 2 && algo != 4) {
+    // automatic: the persistent 256x256 kernel with pipelined reads and spread staging; with the tile queue on (a collective
+    // competes for the CUs) the lockstep form, which has the queue
+    if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? (p.queue_slot >= 0 ? 2 : 5) : 1;
+    if (algo == 5 && p.queue_slot >= 0) algo = 2;
+    if (p.colsum && algo != 2 && algo != 4 && algo != 5) {
         // only the persistent 256x256 kernel fuses the column sums; other paths add them with the stand-alone pass
         if (out_dtype != CHB_OUT_BF16) return CHB_EUNSUPPORTED;
         float* cs = p.colsum;
@@ -1626,6 +1880,22 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
         const dim3 g(grid), block(512);
         if (out_dtype == CHB_OUT_F32) hipLaunchKernelGGL((gemm_nt256pp_kernel<EPI, CHB_OUT_F32>), g, block, 0, s, p);
         else hipLaunchKernelGGL((gemm_nt256pp_kernel<EPI, CHB_OUT_BF16>), g, block, 0, s, p);
+        return CHB_OK;
+    }
+    if (algo == 5) {     // software-pipelined fragment reads (no tile queue)
+        p.tiles_m = chb_div_up(p.M, 256);
+        p.tiles_n = chb_div_up(p.N, 256);
+        int grid = num_cus() & ~7;
+        if (grid < 8) grid = 8;
+        const dim3 g(grid), block(512);
+        const bool fast = !(p.M & 255) && !(p.N & 255) && (out_dtype == CHB_OUT_F32 || (!(p.ldc & 7) && !(p.aux && (p.ld_aux & 7))));
+        if (out_dtype == CHB_OUT_F32) {
+            if (fast) hipLaunchKernelGGL((gemm_nt256sp_kernel<EPI, CHB_OUT_F32, true>), g, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_nt256sp_kernel<EPI, CHB_OUT_F32, false>), g, block, 0, s, p);
+        } else {
+            if (fast) hipLaunchKernelGGL((gemm_nt256sp_kernel<EPI, CHB_OUT_BF16, true>), g, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_nt256sp_kernel<EPI, CHB_OUT_BF16, false>), g, block, 0, s, p);
+        }
         return CHB_OK;
     }
     if (algo == 2) {

@@ -218,16 +218,19 @@ def test_persistent_gemm_schedules_agree_bit_for_bit(m, n, k, epi):
 
     try:
         _lib.set_option("GEMM_TILE_QUEUE", 0)
+        _lib.set_option("GEMM_ALGO", 0)
         ref, ref_aux = run()
         assert not torch.isnan(ref.float()).any()
-        _lib.set_option("GEMM_TILE_QUEUE", 1)
+        _lib.set_option("GEMM_TILE_QUEUE", 1)       # the lockstep kernel with its per-XCD tile queue
         for _ in range(70):
             out, aux = run()
             assert torch.equal(out, ref) and (aux is None or torch.equal(aux, ref_aux))
-        _lib.set_option("GEMM_ALGO", 4)
-        for _ in range(3):
-            out, aux = run()
-            assert torch.equal(out, ref) and (aux is None or torch.equal(aux, ref_aux))
+        _lib.set_option("GEMM_TILE_QUEUE", 0)
+        for algo in (2, 4, 5):       # lockstep (static shares); ping-pong; pipelined reads + spread staging (the default, = ref)
+            _lib.set_option("GEMM_ALGO", algo)
+            for _ in range(3):
+                out, aux = run()
+                assert torch.equal(out, ref) and (aux is None or torch.equal(aux, ref_aux))
     finally:
         _lib.set_option("GEMM_ALGO", 0)
         _lib.set_option("GEMM_TILE_QUEUE", 0)

@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
+from chambers_amd import _build
+if os.environ.get("CHB_AB_LIB"):        # A/B builds of the library (tools/ab_build.sh), this tool only
+    _build.LIB_PATH = os.path.abspath(os.environ["CHB_AB_LIB"])
 from chambers_amd import _lib, kernels as K
 
 A_ALGO = int(sys.argv[1]) if len(sys.argv) > 1 else 2

@@ -27,6 +27,7 @@ for name, m, n, k, epi in SHAPES:
     bias = torch.randn(n, device="cuda")
     out = torch.empty(m, n, dtype=torch.float32 if epi == K.EPI_RESID else torch.bfloat16, device="cuda")
     resid = torch.randn(m, n, device="cuda") if epi == K.EPI_RESID else None
+    _lib.set_option("GEMM_ALGO", int(os.environ.get("PHASES_ALGO", "2")))
     fn = lambda: K.gemm_nt(a, b, out, bias=bias, epilogue=epi, resid=resid, drop_rate=0.1 if epi == K.EPI_RESID else 0.0, drop_key=5)
     for _ in range(200):
         fn()
