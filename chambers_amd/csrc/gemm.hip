@@ -369,13 +369,20 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
                 orow[k] = (int64_t)bi * (p.period + p.n_special) + p.n_special + pp;
             }
         }
+        float4_t t[NK][NQ];
+#ifdef CHB_ABL_NOLDS      // ablation (wrong values): no trip through the LDS scratch
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) t[k][q] = acc[a][(k * NQ + q) & 3];
+#else
 #pragma unroll
         for (int b = 0; b < 4; ++b) *reinterpret_cast<float4_t*>(wr[b]) = acc[a][b];
-        float4_t t[NK][NQ];
 #pragma unroll
         for (int k = 0; k < NK; ++k)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[k][q] = *reinterpret_cast<const float4_t*>(rd[k][q]);
+#endif
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int rr = a * 16 + RPI * k;
@@ -426,7 +433,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
                 }
             }
             char* dst = (EPI == CHB_EPI_PATCH) ? reinterpret_cast<char*>(p.C) + (orow[k] * p.ldc + col) * ESZ : cbase + rr * cstep;
+#ifdef CHB_ABL_NOSTORE    // ablation: the output stores left out (the values still feed the column sums)
+            if (ok[k] && p.colsum == reinterpret_cast<const float*>(1)) {
+#else
             if (ok[k]) {
+#endif
                 if (OUT == CHB_OUT_F32) {
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 } else if (CW == 8) {
@@ -959,7 +970,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
             else if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        PHASE(4)       // vmcnt
+#ifdef CHB_PHASE_STAMPS   // the step-end wait by position in the tile: K-steps 0, 1, 2 apart from the rest
+        if (cc.kt == 0) { PHASE(3) } else if (cc.kt == 1) { PHASE(2) } else if (cc.kt == 2) { PHASE(6) } else { PHASE(4) }
+#endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         PHASE(5)       // barrier
@@ -1887,6 +1900,7 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
         p.tiles_n = chb_div_up(p.N, 256);
         int grid = num_cus() & ~7;
         if (grid < 8) grid = 8;
+        if (chb_option(CHB_OPT_DEBUG) >= 8) grid = chb_option(CHB_OPT_DEBUG) & ~7;   // timing experiments: fewer workgroups than CUs
         const dim3 g(grid), block(512);
         const bool fast = !(p.M & 255) && !(p.N & 255) && (out_dtype == CHB_OUT_F32 || (!(p.ldc & 7) && !(p.aux && (p.ld_aux & 7))));
         if (out_dtype == CHB_OUT_F32) {

@@ -21,6 +21,9 @@ SHAPES = [("qkv_fwd", M, 2304, 768, K.EPI_NONE), ("fc1_dgrad", M, 768, 3072, K.E
           ("square_8k", 8192, 8192, 8192, K.EPI_NONE)]
 NAMES = ["bookkeeping", "stageA+16 reads+wait", "32 MFMA issue", "8 reads+wait", "vmcnt(0)", "barrier", "stageB+32 MFMA issue",
          "pre-epilogue", "epilogue"]
+if os.environ.get("PHASES_ALGO", "2") == "5":      # the pipelined kernel stamps fewer points (cycles summed over the tile, shown per K-step)
+    NAMES = ["-", "Q3(prev)+Q0+Q1+Q2 incl. barrier 1", "step-end vmcnt, K-step 1 of a tile", "step-end vmcnt, K-step 0", "step-end vmcnt, K-steps 3..",
+             "barrier 2", "step-end vmcnt, K-step 2", "pre-epilogue", "epilogue"]
 for name, m, n, k, epi in SHAPES:
     a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     b = torch.randn(n, k, device="cuda").to(torch.bfloat16)
