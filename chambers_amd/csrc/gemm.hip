@@ -1669,6 +1669,15 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int b = 0; b < 4; ++b) yo[b] = r0 * 128 + ((((ycol + b * 16) >> 3) + (pp >> 1)) ^ sw) * 8 + 4 * (pp & 1);
     }
 
+    // FAST: wave-uniform byte pointers of the two staging streams (X one K-step ahead, dY two), moved by one K-step of rows per
+    // iteration - a piece is then one 64-bit add in front of the LDS-DMA, not a 64-bit multiply-add chain per half-tile
+    const int64_t xstep = (int64_t)64 * p.ldx * 2, ystep = (int64_t)64 * p.ldy * 2;
+    const char* xnext = reinterpret_cast<const char*>(p.X + (int64_t)(s_begin + 1) * 64 * p.ldx + k0);
+    const char* ynext = reinterpret_cast<const char*>(p.Y + (int64_t)(s_begin + 2) * 64 * p.ldy + n0);
+    auto stage_fast = [&](const char* base, const uint32_t (&off)[2], bf16_t* lds_half) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(reinterpret_cast<const bf16_t*>(base + off[j]), lds_half + (j * 8 + wave) * 512);
+    };
     for (int s = 0; s < total; ++s) {
         bf16_t* ring = smem + (s & 1) * 4 * 8192;
         bf16_t* nring = smem + ((s + 1) & 1) * 4 * 8192;
@@ -1687,7 +1696,10 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[a] + ks * 32 * 128);
-        if (have1) stage_half_tn_t<FAST>(p.X, p.ldx, m1, k0, p.Kd, offx, nring + 0 * 8192, wave, lane);
+        if (have1) {
+            if (FAST) stage_fast(xnext, offx, nring + 0 * 8192);
+            else stage_half_tn(p.X, p.ldx, m1, k0, p.Kd, nring + 0 * 8192, wave, lane);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
         __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
@@ -1712,7 +1724,10 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) y1[b][ks] = frag_tn_at(Ys + yo[2 + b] + ks * 32 * 128);
-        if (have1) stage_half_tn_t<FAST>(p.X, p.ldx, m1, k0 + 128, p.Kd, offx, nring + 1 * 8192, wave, lane);
+        if (have1) {
+            if (FAST) stage_fast(xnext + 256, offx, nring + 1 * 8192);
+            else stage_half_tn(p.X, p.ldx, m1, k0 + 128, p.Kd, nring + 1 * 8192, wave, lane);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
         __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
@@ -1737,7 +1752,10 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[4 + a] + ks * 32 * 128);
-        if (have2) stage_half_tn_t<FAST>(p.Y, p.ldy, m2, n0, p.Nd, offy, ring + 2 * 8192, wave, lane);
+        if (have2) {
+            if (FAST) stage_fast(ynext, offy, ring + 2 * 8192);
+            else stage_half_tn(p.Y, p.ldy, m2, n0, p.Nd, ring + 2 * 8192, wave, lane);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
         __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
         __builtin_amdgcn_s_setprio(1);
@@ -1753,7 +1771,8 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 
         // phase 4: (kd 64-127, nd 0-31); retire step s+1's loads
         if (have2) {
-            stage_half_tn_t<FAST>(p.Y, p.ldy, m2, n0 + 128, p.Nd, offy, ring + 3 * 8192, wave, lane);
+            if (FAST) stage_fast(ynext + 256, offy, ring + 3 * 8192);
+            else stage_half_tn(p.Y, p.ldy, m2, n0 + 128, p.Nd, ring + 3 * 8192, wave, lane);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1771,6 +1790,8 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         __builtin_amdgcn_sched_barrier(0);
         // (no barrier: the next step's restaging of this ring's X slots is ordered by the barrier after the counted wait above —
         //  every wave completed its phase-3 reads before reaching it)
+        xnext += xstep;
+        ynext += ystep;
     }
 
     // acc[a][b][r]: kd = k0 + wk*128 + a*16 + i, nd = n0 + wn*64 + b*16 + 4g + r.  Stage one 16(kd) x 64(nd) tile row
