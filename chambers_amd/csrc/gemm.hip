@@ -822,7 +822,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
     TileWalk w;
     tile_walk_init(w, p);
     if (w.slot >= w.cnt) return;
-    w.dyn = 0;
+    // Tile queue as in gemm_nt256_kernel (K >= 8 K-tiles): the ticket for tile j+1 is drawn by wave 0 behind barrier 2 of K-step
+    // k0 = slot & 3 of tile j; it is older than everything the step-end wait of K-step k0+1 leaves in flight, so it has returned
+    // by then: wave 0 hands it over through word 0 of its idle epilogue scratch in front of that step's barrier 2, every wave picks
+    // it up behind the barrier - the staging stream enters tile j+1 at K-step ntk-2.
+    w.dyn = (p.queue_slot >= 0 && w.ntk >= 8) ? 1 : 0;
+    const int q_k0 = w.slot & 3;
+    int* q_ctr = &g_tile_ctr[w.dyn ? p.queue_slot : 0][blockIdx.x & 7];
+    int* q_lds = reinterpret_cast<int*>(smem + 2 * 4 * 8192);
+    int q_ticket = 0;
 
     uint32_t offa[2], offb[2];
 #pragma unroll
@@ -842,15 +850,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
     const char* pa = nullptr;
     const char* pb = nullptr;
     const int64_t a_half = (int64_t)128 * p.lda * 2, b_half = (int64_t)128 * p.ldb * 2;
-    auto stream_set = [&]() {
-        pa = reinterpret_cast<const char*>(p.A + (int64_t)cs.m0 * p.lda + cs.kt * BK);
-        pb = reinterpret_cast<const char*>(p.B + (int64_t)cs.n0 * p.ldb + cs.kt * BK);
-    };
-    auto stream_next = [&]() {
-        cursor_next(cs, w);
-        if (cs.kt == 0) stream_set();
-        else { pa += BK * 2; pb += BK * 2; }
-    };
+    // (macros, not lambdas: a by-reference capture of the tile walk, which the tile queue writes to, sends it to scratch memory)
+#define STREAM_SET() { pa = reinterpret_cast<const char*>(p.A + (int64_t)cs.m0 * p.lda + cs.kt * BK); \
+                       pb = reinterpret_cast<const char*>(p.B + (int64_t)cs.n0 * p.ldb + cs.kt * BK); }
+#define STREAM_NEXT() { cursor_next(cs, w); if (cs.kt == 0) STREAM_SET() else { pa += BK * 2; pb += BK * 2; } }
     // piece e of a step: e = 0..3 -> B (half e >> 1, instruction e & 1), e = 4..7 -> A; instruction 0 of a half = its rows 0-63
     auto piece = [&](int e, bf16_t* ring_) {
         const int h = (e >> 1) & 1, j = e & 1;
@@ -868,14 +871,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) piece(e, ring_);
     };
-    stream_set();
+    STREAM_SET()
     stage_step(smem);
-    stream_next();
+    STREAM_NEXT()
     if (cs.valid) stage_step(smem + 4 * 8192);
     // ragged halves issue a different number of LDS-DMA instructions: only the full-tile build may count
     if (FAST && cs.valid) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stream_next();
+    STREAM_NEXT()
     __builtin_amdgcn_s_barrier();
 
     float4_t acc[8][4];
@@ -973,9 +976,33 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
 #ifdef CHB_PHASE_STAMPS   // the step-end wait by position in the tile: K-steps 0, 1, 2 apart from the rest
         if (cc.kt == 0) { PHASE(3) } else if (cc.kt == 1) { PHASE(2) } else if (cc.kt == 2) { PHASE(6) } else { PHASE(4) }
 #endif
+        if (w.dyn && cc.kt == q_k0 + 1 && wave == 0) {     // scalar branch
+            if (lane == 0) {
+                // tickets 0 .. cnt-1 are drawn per XCD and launch (one per tile started): ticket t is tile stride + t of the XCD's
+                // list, and whoever holds the last one leaves the counter clean for the slot's next launch
+                *q_lds = w.stride + q_ticket;
+                if (q_ticket == w.cnt - 1) __hip_atomic_store(q_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the word is in LDS before this wave reaches the barrier
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         PHASE(5)       // barrier
+        if (w.dyn) {
+            if (cc.kt == q_k0 && wave == 0) {      // scalar branch; lane 0 only, in-place operand (see gemm_nt256_kernel)
+                q_ticket = 1;
+                uint64_t save;
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %[t], %[off], %[t], %[ptr] sc0\n\ts_mov_b64 exec, %[sv]"
+                             : [t] "+v"(q_ticket), [sv] "=&s"(save)
+                             : [off] "v"(0), [ptr] "s"(q_ctr)
+                             : "memory");
+            }
+            if (cc.kt == q_k0 + 1) {
+                const int nxt = __builtin_amdgcn_readfirstlane(*q_lds);
+                const int q = (cc.j + 1) & 3;
+                if (q == 0) w.li_tab[0] = nxt; else if (q == 1) w.li_tab[1] = nxt; else if (q == 2) w.li_tab[2] = nxt; else w.li_tab[3] = nxt;
+            }
+        }
         // ---- Q3
         if (!last_k) {
             READ4(bK0, nbA0, 0)
@@ -992,7 +1019,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
             for (int b = 0; b < 4; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bK1[b], aY[a], acc[4 + a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (staging) stream_next();
+        if (staging) STREAM_NEXT()
 
         if (last_k) {
             PHASE(7)
@@ -1016,6 +1043,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
     PHASE_FLUSH
 }
 #undef READ4
+#undef STREAM_SET
+#undef STREAM_NEXT
 
 
 // ---- NT, persistent 256x256 tiles, two wave groups in anti-phase ("ping-pong") ----------------------------------------------
@@ -1880,10 +1909,8 @@ int gemm_algo_override() { return chb_option(CHB_OPT_GEMM_ALGO); }
 template <int EPI>
 int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
     int algo = gemm_algo_override();
-    // automatic: the persistent 256x256 kernel with pipelined reads and spread staging; with the tile queue on (a collective
-    // competes for the CUs) the lockstep form, which has the queue
-    if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? (p.queue_slot >= 0 ? 2 : 5) : 1;
-    if (algo == 5 && p.queue_slot >= 0) algo = 2;
+    // automatic: the persistent 256x256 kernel with pipelined reads and spread staging (both persistent kernels have the tile queue)
+    if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? 5 : 1;
     if (p.colsum && algo != 2 && algo != 4 && algo != 5) {
         // only the persistent 256x256 kernel fuses the column sums; other paths add them with the stand-alone pass
         if (out_dtype != CHB_OUT_BF16) return CHB_EUNSUPPORTED;
@@ -1916,7 +1943,7 @@ int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_nt256pp_kernel<EPI, CHB_OUT_BF16>), g, block, 0, s, p);
         return CHB_OK;
     }
-    if (algo == 5) {     // software-pipelined fragment reads (no tile queue)
+    if (algo == 5) {     // software-pipelined fragment reads, staging spread over the K-step
         p.tiles_m = chb_div_up(p.M, 256);
         p.tiles_n = chb_div_up(p.N, 256);
         int grid = num_cus() & ~7;

@@ -197,9 +197,9 @@ def test_persistent_gemm_gelu_and_dgelu_colsum(m, n, k, out_f32):
 @pytest.mark.parametrize("m,n,k,epi", [(8192, 1024, 768, "resid"), (8192 + 100, 1280, 640, "none"), (16384, 768, 1024, "gelu"),
                                          (4096, 512, 448, "none")])
 def test_persistent_gemm_schedules_agree_bit_for_bit(m, n, k, epi):
-    """The same K order and accumulation order in every schedule of the persistent NT kernel: static tile shares vs the per-XCD
-    tile queue (K >= 8 K-tiles; 70 launches so that every queue slot is used twice and must have been left clean), and the
-    lockstep vs the ping-pong K-loop (full tiles; falls back to lockstep on the ragged shape)."""
+    """The same K order and accumulation order in every schedule of the persistent NT kernels: static tile shares vs the per-XCD
+    tile queue (K >= 8 K-tiles; 70 launches per kernel so that every queue slot is used and must have been left clean), and the
+    pipelined (default) vs lockstep vs ping-pong K-loops (ping-pong: full tiles; falls back to lockstep on the ragged shape)."""
     from chambers_amd import _lib
     from chambers_amd import kernels as K
     a = bf(torch.randn(m, k, generator=g(71))).cuda()
@@ -221,10 +221,12 @@ def test_persistent_gemm_schedules_agree_bit_for_bit(m, n, k, epi):
         _lib.set_option("GEMM_ALGO", 0)
         ref, ref_aux = run()
         assert not torch.isnan(ref.float()).any()
-        _lib.set_option("GEMM_TILE_QUEUE", 1)       # the lockstep kernel with its per-XCD tile queue
-        for _ in range(70):
-            out, aux = run()
-            assert torch.equal(out, ref) and (aux is None or torch.equal(aux, ref_aux))
+        _lib.set_option("GEMM_TILE_QUEUE", 1)       # per-XCD tile queue: the pipelined kernel (automatic), then the lockstep one
+        for algo, reps in ((0, 70), (2, 70)):
+            _lib.set_option("GEMM_ALGO", algo)
+            for _ in range(reps):
+                out, aux = run()
+                assert torch.equal(out, ref) and (aux is None or torch.equal(aux, ref_aux))
         _lib.set_option("GEMM_TILE_QUEUE", 0)
         for algo in (2, 4, 5):       # lockstep (static shares); ping-pong; pipelined reads + spread staging (the default, = ref)
             _lib.set_option("GEMM_ALGO", algo)
