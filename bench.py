@@ -47,16 +47,10 @@ class KernelTimer:
     def __init__(self):
         self.records = []   # (name, work, start_event, stop_event)
         self.enabled = False
-        self.tile_queue = False    # set by main(): the engine switches the NT kernel's tile queue on when its reducer is active
 
     def nt256_name(self):
         algo = int(os.environ.get("CHB_GEMM_ALGO", "0"))
-        queue = self.tile_queue or os.environ.get("CHB_GEMM_TILE_QUEUE", "0") not in ("", "0")
-        if algo == 4:
-            return "gemm_nt256pp_kernel"
-        if algo in (0, 5) and not queue:
-            return "gemm_nt256sp_kernel"
-        return "gemm_nt256_kernel"
+        return {0: "gemm_nt256sp_kernel", 5: "gemm_nt256sp_kernel", 4: "gemm_nt256pp_kernel"}.get(algo, "gemm_nt256_kernel")
 
     def wrap(self, K):
         timer = self
@@ -67,7 +61,7 @@ class KernelTimer:
                 return orig_nt(a, b, out, m=m, **kw)
             mm = a.shape[0] if m is None else m
             # same selection rule as csrc/gemm.hip launch_nt(): persistent 256x256 tiles for large problems - the pipelined kernel
-            # (gemm_nt256sp_kernel), or the lockstep one when its tile queue is on (data-parallel runs) or CHB_GEMM_ALGO asks for it
+            # (gemm_nt256sp_kernel) unless CHB_GEMM_ALGO asks for another schedule
             fam = timer.nt256_name() if (mm >= 2048 and b.shape[0] >= 256) else "gemm_nt_kernel"
             name = "%s<%d, %d>" % (fam, kw.get("epilogue", 0), 1 if out.dtype == torch.float32 else 0)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -374,7 +368,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     red = eng.reducer
-    timer.tile_queue = bool(red.active)
     red.measure = True
     red.n_collectives = red.bytes_reduced = 0
     timer.enabled = True

@@ -433,8 +433,8 @@ class ViTEngine:
             self.reducer = GradBucketReducer(self.G, self.buckets, process_group)
             if self.reducer.active:
                 # a collective's kernel takes CUs from whatever launch it lands on: with the tile queue the persistent GEMM's
-                # late workgroups draw fewer tiles instead of stretching the launch by the collective's duration (costs the
-                # GEMMs ~2 % when nothing competes, so it stays off for single-GPU runs; tools/rccl_contention.py)
+                # late workgroups draw fewer tiles instead of stretching the launch by the collective's duration (within
+                # +-1 % per GEMM when nothing competes; off for single-GPU runs; tools/rccl_contention.py)
                 _lib.set_option("GEMM_TILE_QUEUE", 1)
             self._g_clean = True        # G holds zeros (allocation, or the last AdamW launch cleared it behind its read)
         mats = [s for s in self.specs if s.matrix]
