@@ -48,9 +48,11 @@ class KernelTimer:
         self.records = []   # (name, work, start_event, stop_event)
         self.enabled = False
 
-    def nt256_name(self):
+    def nt256_name(self, m, n):
         algo = int(os.environ.get("CHB_GEMM_ALGO", "0"))
-        return {0: "gemm_nt256sp_kernel", 5: "gemm_nt256sp_kernel", 4: "gemm_nt256pp_kernel"}.get(algo, "gemm_nt256_kernel")
+        if algo == 0:       # csrc/gemm.hip launch_nt(): the pipelined kernel where every tile is full, the lockstep one on ragged shapes
+            algo = 5 if (m % 256 == 0 and n % 256 == 0) else 2
+        return {5: "gemm_nt256sp_kernel", 4: "gemm_nt256pp_kernel"}.get(algo, "gemm_nt256_kernel")
 
     def wrap(self, K):
         timer = self
@@ -62,7 +64,7 @@ class KernelTimer:
             mm = a.shape[0] if m is None else m
             # same selection rule as csrc/gemm.hip launch_nt(): persistent 256x256 tiles for large problems - the pipelined kernel
             # (gemm_nt256sp_kernel) unless CHB_GEMM_ALGO asks for another schedule
-            fam = timer.nt256_name() if (mm >= 2048 and b.shape[0] >= 256) else "gemm_nt_kernel"
+            fam = timer.nt256_name(mm, b.shape[0]) if (mm >= 2048 and b.shape[0] >= 256) else "gemm_nt_kernel"
             name = "%s<%d, %d>" % (fam, kw.get("epilogue", 0), 1 if out.dtype == torch.float32 else 0)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()

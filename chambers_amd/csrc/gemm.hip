@@ -26,7 +26,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 #define EPI_DEPTH_RESID 1
 #endif
 #ifndef EPI_DEPTH_DGELU
-#define EPI_DEPTH_DGELU 0
+#define EPI_DEPTH_DGELU 1
+#endif
+#ifndef EPI_DEPTH_DGELU_WIDE
+#define EPI_DEPTH_DGELU_WIDE 0     // the 8-column form: one row ahead costs 8 more registers per lane and spills
 #endif
 constexpr int TILE_ELEMS = 128 * 64;  // one operand tile, either orientation
 
@@ -264,11 +267,150 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmParams p) {
 // chunks of 4 columns), so that EVERY global access of the epilogue (residual / saved pre-activation
 // loads, output and aux stores) is 4 rows x 128..256 contiguous bytes per wave-instruction instead of
 // 16 rows x 32 bytes.  The scratch is XOR-swizzled (16-byte chunk ^ row) - conflict-free both ways.
+template <int EPI, int OUT, bool GUARD, int A0, int A1>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stage, int m_base, int n_base, float4_t (&acc)[8][4],
+                                                int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int cr = lane >> 4, c4 = lane & 15;
+    const int col = n_base + c4 * 4;
+    const bool colok = !GUARD || col < p.N;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && colok) bias = *reinterpret_cast<const float4*>(p.bias + col);
+    // lane-constant pieces of every address (the per-(a,k) part is a compile-time row count times a uniform stride)
+    constexpr int ESZ = (OUT == CHB_OUT_F32) ? 4 : 2;
+    const int64_t row0 = (int64_t)m_base + cr;
+    char* cbase = reinterpret_cast<char*>(p.C) + (row0 * p.ldc + col) * ESZ;
+    const int64_t cstep = p.ldc * ESZ;
+    const char* rbase = (EPI == CHB_EPI_RESID) ? reinterpret_cast<const char*>(p.resid) + (row0 * p.ld_resid + col) * 4 : nullptr;
+    const int64_t rstep = p.ld_resid * 4;
+    char* abase = (EPI == CHB_EPI_GELU || EPI == CHB_EPI_DGELU) ? reinterpret_cast<char*>(p.aux) + (row0 * p.ld_aux + col) * 2 : nullptr;
+    const int64_t astep = p.ld_aux * 2;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    float* wr[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wr[b] = stage + i * 64 + (((4 * b + g) ^ i) << 2);
+    const float* rd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rd[k] = stage + (4 * k + cr) * 64 + ((c4 ^ (4 * k + cr)) << 2);
+    // The epilogue's own global loads (residual / saved gelu' / positional rows) run DEPTH tile rows ahead: the loads of row
+    // a + DEPTH are issued before row a crosses LDS.  Measured (tools/ab_build.sh, depths 0-5 A/B in one session): no depth
+    // changes the wall time of any shape by more than run-to-run noise (+-2 %) - the epilogue is not waiting on these loads.
+    constexpr bool HAS_IN = (EPI == CHB_EPI_PATCH || EPI == CHB_EPI_RESID || EPI == CHB_EPI_DGELU);
+    constexpr int DEPTH = (EPI == CHB_EPI_RESID) ? EPI_DEPTH_RESID : (EPI == CHB_EPI_DGELU) ? EPI_DEPTH_DGELU : 1;   // rows in flight ahead
+    float4 r4buf[DEPTH + 1][4];
+    uint2 a2buf[DEPTH + 1][4];
+    auto load_inputs = [&](int a, float4 (&r4)[4], uint2 (&a2)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rr = a * 16 + 4 * k;
+            const int row = m_base + rr + cr;
+            const bool okk = colok && (!GUARD || row < p.M);
+            if (EPI == CHB_EPI_PATCH) {
+                const int bi = row / p.period, pp = row - bi * p.period;
+                if (okk) r4[k] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.n_special + pp) * p.ld_resid + col);
+            }
+            if (EPI == CHB_EPI_RESID && okk) r4[k] = *reinterpret_cast<const float4*>(rbase + rr * rstep);
+            if (EPI == CHB_EPI_DGELU && okk) a2[k] = *reinterpret_cast<const uint2*>(abase + rr * astep);
+        }
+    };
+    if (HAS_IN) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (A0 + d < A1) load_inputs(A0 + d, r4buf[d % (DEPTH + 1)], a2buf[d % (DEPTH + 1)]);
+    }
+#pragma unroll
+    for (int a = A0; a < A1; ++a) {
+        float4 (&r4)[4] = r4buf[(a - A0) % (DEPTH + 1)];
+        uint2 (&a2)[4] = a2buf[(a - A0) % (DEPTH + 1)];
+        if (HAS_IN && a + DEPTH < A1) load_inputs(a + DEPTH, r4buf[(a + DEPTH - A0) % (DEPTH + 1)], a2buf[(a + DEPTH - A0) % (DEPTH + 1)]);
+        int64_t orow[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rr = a * 16 + 4 * k;                      // compile-time row offset inside the wave's 128 rows
+            const int row = m_base + rr + cr;
+            orow[k] = row;
+            ok[k] = colok && (!GUARD || row < p.M);
+            if (EPI == CHB_EPI_PATCH) {
+                const int bi = row / p.period, pp = row - bi * p.period;
+                orow[k] = (int64_t)bi * (p.period + p.n_special) + p.n_special + pp;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<float4_t*>(wr[b]) = acc[a][b];
+        float4_t t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const float4_t*>(rd[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rr = a * 16 + 4 * k;
+            float v[4] = {t[k][0] + bias.x, t[k][1] + bias.y, t[k][2] + bias.z, t[k][3] + bias.w};
+            if (EPI == CHB_EPI_GELU) {
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], d[e]);
+                uint2 der;
+                der.x = pack_bf16x2(d[0], d[1]);
+                der.y = pack_bf16x2(d[2], d[3]);
+                if (ok[k]) *reinterpret_cast<uint2*>(abase + rr * astep) = der;
+            } else if (EPI == CHB_EPI_DGELU) {
+                v[0] *= bf16_to_f32((bf16_t)(a2[k].x & 0xffff));
+                v[1] *= bf16_to_f32((bf16_t)(a2[k].x >> 16));
+                v[2] *= bf16_to_f32((bf16_t)(a2[k].y & 0xffff));
+                v[3] *= bf16_to_f32((bf16_t)(a2[k].y >> 16));
+            } else if (EPI == CHB_EPI_RESID || EPI == CHB_EPI_PATCH) {
+                if (EPI == CHB_EPI_PATCH) {
+                    v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;
+                }
+                if (p.drop_thr) {
+                    const uint64_t e0 = (uint64_t)orow[k] * (uint64_t)p.N + (uint64_t)col;
+                    bool k0, k1, k2, k3;
+                    chb_keep2((uint32_t)(e0 >> 1), p.drop_key, p.drop_thr, k0, k1);
+                    chb_keep2((uint32_t)(e0 >> 1) + 1u, p.drop_key, p.drop_thr, k2, k3);
+                    v[0] = k0 ? v[0] * p.drop_scale : 0.0f;
+                    v[1] = k1 ? v[1] * p.drop_scale : 0.0f;
+                    v[2] = k2 ? v[2] * p.drop_scale : 0.0f;
+                    v[3] = k3 ? v[3] * p.drop_scale : 0.0f;
+                }
+                if (EPI == CHB_EPI_RESID) {
+                    v[0] += r4[k].x; v[1] += r4[k].y; v[2] += r4[k].z; v[3] += r4[k].w;
+                }
+            }
+            char* dst = (EPI == CHB_EPI_PATCH) ? reinterpret_cast<char*>(p.C) + (orow[k] * p.ldc + col) * ESZ : cbase + rr * cstep;
+            if (ok[k]) {
+                if (OUT == CHB_OUT_F32) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = o;
+                }
+                csum[0] += v[0]; csum[1] += v[1]; csum[2] += v[2]; csum[3] += v[3];
+            }
+            // keep the erf polynomial of one 4-element group from being interleaved with the next three: the wider schedule
+            // needs more than the 256 registers a wave has here and spills (measured: 0.82 -> 0.73 ms on the fc1 GEMM)
+            if (EPI == CHB_EPI_GELU) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (p.colsum) {   // this wave's 128 rows x 64 columns: fold the 4 row-groups (lanes cr) and add once per column
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            csum[e] += __shfl_xor(csum[e], 16, 64);
+            csum[e] += __shfl_xor(csum[e], 32, 64);
+        }
+        if (cr == 0 && colok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(p.colsum + col + e, csum[e]);
+        }
+    }
+}
+// The same for full-tile builds (FAST): written for a generic number of columns per lane.
 // WIDE (bf16 outputs whose rows are 16-byte aligned): a lane owns EIGHT consecutive columns (8 lanes per row, 8 rows per
 // wave-instruction) so that bf16 rows and the saved gelu' rows also move as 16 bytes per lane - the store tail is bound by the
 // number of store instructions, not by their bytes (cdna_hip_programming.md T21): 16 instead of 32 per wave and output tile.
-template <int EPI, int OUT, bool GUARD, int A0, int A1, bool WIDE = false>
-__device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stage, int m_base, int n_base, float4_t (&acc)[8][4],
+template <int EPI, int OUT, bool GUARD, int A0, int A1, bool WIDE = true>
+__device__ __forceinline__ void epilogue_staged_wide(const GemmParams& p, float* stage, int m_base, int n_base, float4_t (&acc)[8][4],
                                                 int lane) {
     constexpr int CW = (WIDE && OUT == CHB_OUT_BF16) ? 8 : 4;   // columns per lane
     constexpr int NQ = CW / 4;                                   // 16-byte scratch chunks per lane and row
@@ -315,7 +457,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, float* stag
     // a + DEPTH are issued before row a crosses LDS.  Measured (tools/ab_build.sh, depths 0-5 A/B in one session): no depth
     // changes the wall time of any shape by more than run-to-run noise (+-2 %) - the epilogue is not waiting on these loads.
     constexpr bool HAS_IN = (EPI == CHB_EPI_PATCH || EPI == CHB_EPI_RESID || EPI == CHB_EPI_DGELU);
-    constexpr int DEPTH = (EPI == CHB_EPI_RESID) ? EPI_DEPTH_RESID : (EPI == CHB_EPI_DGELU) ? EPI_DEPTH_DGELU : 1;   // rows in flight ahead
+    constexpr int DEPTH = (EPI == CHB_EPI_RESID) ? EPI_DEPTH_RESID : (EPI == CHB_EPI_DGELU) ? EPI_DEPTH_DGELU_WIDE : 1;   // rows in flight ahead
     float4 r4buf[DEPTH + 1][NK][NQ];
     uint32_t a2buf[DEPTH + 1][NK][CW / 2];
     auto load_inputs = [&](int a, float4 (&r4)[NK][NQ], uint32_t (&a2)[NK][CW / 2]) {
@@ -757,7 +899,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         // ---------------- end of an output tile: epilogue (later steps' loads keep flying)
         if (last_k) {
             PHASE(7)
-            if (FAST) epilogue_staged<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            if (FAST) epilogue_staged_wide<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             else if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
 #pragma unroll
@@ -1023,7 +1165,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
 
         if (last_k) {
             PHASE(7)
-            if (FAST) epilogue_staged<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            if (FAST) epilogue_staged_wide<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             else if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
 #pragma unroll
@@ -1193,7 +1335,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256pp_kernel(GemmParams p) {
         CHB_PP_SYNC_MFMA(4, 0, 1, (T & 1) * 4 + 1)
 
         if (last_k) {
-            epilogue_staged<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + grp * 128, cc.n0 + wn * 64, acc, lane);
+            epilogue_staged_wide<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + grp * 128, cc.n0 + wn * 64, acc, lane);
             // leave only (at most) the epilogue's own memory operations outstanding: every staging element issued before it has landed
             constexpr int EPI_OPS = (EPI == CHB_EPI_NONE) ? 32 : 63;
             if (EPI_OPS == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -1909,8 +2051,10 @@ int gemm_algo_override() { return chb_option(CHB_OPT_GEMM_ALGO); }
 template <int EPI>
 int launch_nt(GemmParams p, int out_dtype, hipStream_t s) {
     int algo = gemm_algo_override();
-    // automatic: the persistent 256x256 kernel with pipelined reads and spread staging (both persistent kernels have the tile queue)
-    if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? 5 : 1;
+    // automatic: the persistent 256x256 kernel with pipelined reads and spread staging where every tile is full (both persistent kernels
+    // have the tile queue)
+    const bool full_tiles = !(p.M & 255) && !(p.N & 255) && (out_dtype == CHB_OUT_F32 || (!(p.ldc & 7) && !(p.aux && (p.ld_aux & 7))));
+    if (algo == 0) algo = (p.M >= 2048 && p.N >= 256) ? (full_tiles ? 5 : 2) : 1;      // ragged shapes: the lockstep kernel is the faster one
     if (p.colsum && algo != 2 && algo != 4 && algo != 5) {
         // only the persistent 256x256 kernel fuses the column sums; other paths add them with the stand-alone pass
         if (out_dtype != CHB_OUT_BF16) return CHB_EUNSUPPORTED;

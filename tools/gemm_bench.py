@@ -7,7 +7,7 @@ if os.environ.get("CHB_AB_LIB"):        # A/B builds of the library (tools/ab_bu
     _build.LIB_PATH = os.path.abspath(os.environ["CHB_AB_LIB"])
 from chambers_amd import _lib, kernels as K
 
-M = 512 * 197
+M = int(os.environ.get("GEMM_BENCH_M", str(512 * 197)))
 SHAPES_NT = [("qkv_fwd", M, 2304, 768, K.EPI_NONE), ("proj_fwd", M, 768, 768, K.EPI_RESID), ("fc1_fwd", M, 3072, 768, K.EPI_GELU),
              ("fc2_fwd", M, 768, 3072, K.EPI_RESID), ("fc2_dgrad", M, 3072, 768, K.EPI_DGELU), ("fc1_dgrad", M, 768, 3072, K.EPI_NONE),
              ("qkv_dgrad", M, 768, 2304, K.EPI_NONE)]
