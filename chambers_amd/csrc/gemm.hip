@@ -899,8 +899,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         // ---------------- end of an output tile: epilogue (later steps' loads keep flying)
         if (last_k) {
             PHASE(7)
-            if (FAST) epilogue_staged_wide<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
-            else if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            if (FAST && EPI != CHB_EPI_DGELU) epilogue_staged_wide<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);   // (gelu'-multiply: the 4-column form with its inputs one row ahead is the faster one)
+            else if (FAST || interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
 #pragma unroll
             for (int a = 0; a < 8; ++a)
@@ -1165,8 +1165,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
 
         if (last_k) {
             PHASE(7)
-            if (FAST) epilogue_staged_wide<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
-            else if (interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
+            if (FAST && EPI != CHB_EPI_DGELU) epilogue_staged_wide<EPI, OUT, false, 0, 8, true>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);   // (gelu'-multiply: the 4-column form with its inputs one row ahead is the faster one)
+            else if (FAST || interior) epilogue_staged<EPI, OUT, false, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
             else epilogue_staged<EPI, OUT, true, 0, 8>(p, stage, cc.m0 + wm * 128, cc.n0 + wn * 64, acc, lane);
 #pragma unroll
             for (int a = 0; a < 8; ++a)
