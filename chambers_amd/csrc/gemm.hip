@@ -1385,6 +1385,15 @@ __device__ __forceinline__ bf16x8_t frag_tn(const bf16_t* lds_tile, int mb, int 
 }
 
 // the same fragment from a precomputed lane address: rows +0..3 at p, rows +4..7 at p + 4 rows
+// the same pair of transposed reads as inline asm (see gemm_nt256sp_kernel: reads the compiler cannot count are counted by hand)
+template <int OFF>
+__device__ __forceinline__ void tr_read128(bf16x8_t& d, uint32_t addr) {
+    short4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 1024));
+    const short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    d = __builtin_bit_cast(bf16x8_t, v);
+}
 __device__ __forceinline__ bf16x8_t frag_tn_at(const bf16_t* p) {
     const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)p);
     const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(p + 4 * 128));
@@ -1849,30 +1858,47 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) glds16(reinterpret_cast<const bf16_t*>(base + off[j]), lds_half + (j * 8 + wave) * 512);
     };
+    // Fragment reads run AHEAD of the MFMAs that use them (tools ablation: without any reads the kernel is 27 % faster, the reads
+    // were a burst in front of every 16-MFMA block): inline asm transposed reads with hand-counted lgkmcnt, as in
+    // gemm_nt256sp_kernel (hipcc turns every LDS wait into lgkmcnt(0) while an LDS-DMA is in flight).  Same 64 fragment registers:
+    //   phase 1 issues y1 (phase 2's dY columns);  phase 2 re-loads each k-half of xf with kd rows 64-127 as soon as its MFMAs on
+    //   that half are issued (phase 3's X);  phase 4 does the same with the NEXT step's kd rows 0-63 and dY columns 0-31.
+    // Same MFMA order per accumulator as before.
+    uint32_t xadr[8], yadr[4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) xadr[a] = lds_addr(smem + wk * 8192 + xo[a]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) yadr[b] = lds_addr(smem + (2 + (wn >> 1)) * 8192 + yo[b]);
+    bf16x8_t xf[4][2], y0[2][2], y1[2][2];
+#define TN_WAIT_X(n, k) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(xf[0][k]), "+v"(xf[1][k]), "+v"(xf[2][k]), "+v"(xf[3][k]));
+#define TN_WAIT_Y(n, y) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(y[0][0]), "+v"(y[0][1]), "+v"(y[1][0]), "+v"(y[1][1]));
+    // first step: kd rows 0-63 and dY columns 0-31 of ring 0 (landed: the prologue's barrier)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { if (ks == 0) tr_read128<0>(xf[a][0], xadr[a]); else tr_read128<8192>(xf[a][1], xadr[a]); }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { if (ks == 0) tr_read128<0>(y0[b][0], yadr[b]); else tr_read128<8192>(y0[b][1], yadr[b]); }
+    }
     for (int s = 0; s < total; ++s) {
         bf16_t* ring = smem + (s & 1) * 4 * 8192;
         bf16_t* nring = smem + ((s + 1) & 1) * 4 * 8192;
-        const bf16_t* Xs = ring + wk * 8192;
-        const bf16_t* Ys = ring + (2 + (wn >> 1)) * 8192;
+        const uint32_t ro = (s & 1) * 65536, nro = 65536 - ro;
         const bool have1 = s + 1 < total, have2 = s + 2 < total;
         const int m1 = (s_begin + s + 1) * 64, m2 = (s_begin + s + 2) * 64;
-        bf16x8_t xf[4][2], y0[2][2], y1[2][2];
 
-        // phase 1: (kd 0-63, nd 0-31)
+        // phase 1: (kd 0-63, nd 0-31).  In flight on entry: xf (16 reads), y0 (8 reads).
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) y0[b][ks] = frag_tn_at(Ys + yo[b] + ks * 32 * 128);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[a] + ks * 32 * 128);
+        for (int b = 0; b < 2; ++b) {
+            tr_read128<0>(y1[b][0], yadr[2 + b] + ro);
+            tr_read128<8192>(y1[b][1], yadr[2 + b] + ro);
+        }
         if (have1) {
             if (FAST) stage_fast(xnext, offx, nring + 0 * 8192);
             else stage_half_tn(p.X, p.ldx, m1, k0, p.Kd, nring + 0 * 8192, wave, lane);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
-        __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
+        TN_WAIT_X(8, 0) TN_WAIT_X(8, 1) TN_WAIT_Y(8, y0)
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1888,59 +1914,56 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        // (no barrier: phase 2 restages the OTHER ring's X slots and reads this ring's dY slots, nothing phase 1 still reads)
 
-        // phase 2: (kd 0-63, nd 32-63)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) y1[b][ks] = frag_tn_at(Ys + yo[2 + b] + ks * 32 * 128);
+        // phase 2: (kd 0-63, nd 32-63); each k-half of xf is re-loaded with kd rows 64-127 behind its MFMAs
         if (have1) {
             if (FAST) stage_fast(xnext + 256, offx, nring + 1 * 8192);
             else stage_half_tn(p.X, p.ldx, m1, k0 + 128, p.Kd, nring + 1 * 8192, wave, lane);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
-        __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
-        __builtin_amdgcn_s_setprio(1);
+        TN_WAIT_Y(0, y1)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][ks], xf[a][ks], acc[a][2 + b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { if (ks == 0) tr_read128<0>(xf[a][0], xadr[4 + a] + ro); else tr_read128<8192>(xf[a][1], xadr[4 + a] + ro); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (COLSUM && do_colsum) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) cacc[2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][ks], ones, cacc[2 + b], 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();        // every wave's dY reads of this ring have returned (waited for in phases 1 and 2)
 
         // phase 3: (kd 64-127, nd 32-63); the dY slots of this ring are free now
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xf[a][ks] = frag_tn_at(Xs + xo[4 + a] + ks * 32 * 128);
         if (have2) {
             if (FAST) stage_fast(ynext, offy, ring + 2 * 8192);
             else stage_half_tn(p.Y, p.ldy, m2, n0, p.Nd, ring + 2 * 8192, wave, lane);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no barrier here: the one that closes the phase orders these reads
-        __builtin_amdgcn_sched_barrier(0);                   // before any later restaging of the slots they came from
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0) { TN_WAIT_X(8, 0) } else { TN_WAIT_X(0, 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[4 + a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][ks], xf[a][ks], acc[4 + a][2 + b], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // (no barrier: phase 4 restages the dY slot whose readers all passed the barrier after phase 2)
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
-        // phase 4: (kd 64-127, nd 0-31); retire step s+1's loads
+        // phase 4: (kd 64-127, nd 0-31); retire step s+1's loads, then re-load xf / y0 with the next step's first fragments
         if (have2) {
             if (FAST) stage_fast(ynext + 256, offy, ring + 3 * 8192);
             else stage_half_tn(p.Y, p.ldy, m2, n0 + 128, p.Nd, ring + 3 * 8192, wave, lane);
@@ -1948,22 +1971,31 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(Tn256Params p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();        // step s+1 has landed; every wave's X reads of this ring have returned (phase 3's waits)
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][ks], xf[a][ks], acc[4 + a][b], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // (no barrier: the next step's restaging of this ring's X slots is ordered by the barrier after the counted wait above —
-        //  every wave completed its phase-3 reads before reaching it)
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (have1) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { if (ks == 0) tr_read128<0>(xf[a][0], xadr[a] + nro); else tr_read128<8192>(xf[a][1], xadr[a] + nro); }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) { if (ks == 0) tr_read128<0>(y0[b][0], yadr[b] + nro); else tr_read128<8192>(y0[b][1], yadr[b] + nro); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         xnext += xstep;
         ynext += ystep;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef TN_WAIT_X
+#undef TN_WAIT_Y
 
     // acc[a][b][r]: kd = k0 + wk*128 + a*16 + i, nd = n0 + wn*64 + b*16 + 4g + r.  Stage one 16(kd) x 64(nd) tile row
     // at a time and add it as 16 full 256-byte rows.
