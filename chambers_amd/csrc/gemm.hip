@@ -1017,8 +1017,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
     stage_step(smem);
     STREAM_NEXT()
     if (cs.valid) stage_step(smem + 4 * 8192);
-    // ragged halves issue a different number of LDS-DMA instructions: only the full-tile build may count
-    if (FAST && cs.valid) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (cs.valid) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // a piece is ONE instruction in every build (ragged ones clamp rows)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STREAM_NEXT()
     __builtin_amdgcn_s_barrier();
@@ -1102,11 +1101,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
         }
         // ---- barrier 2: this ring is read out, step s+1 has landed.  The counter retires in issue order: what may stay in flight
         // is what was issued AFTER the last LDS-DMA of step s+1 - this step's six early pieces and, behind a tile's epilogue, its
-        // loads and stores.  Ragged builds issue a varying number of instructions per piece and wait for everything.
+        // loads and stores.
         asm volatile("s_waitcnt lgkmcnt(0)" : FRAG4(aY) : : "memory");
         PHASE(1)       // Q3 of the previous step, bookkeeping, Q0, Q1, Q2 and the last reads' wait
         {
-            const int young = !FAST ? 0 : (staging ? 6 : 0) + (first_k ? EPI_OPS : 0);
+            const int young = (staging ? 6 : 0) + (first_k ? EPI_OPS : 0);     // ragged builds: EPI_OPS = 0 (a guarded epilogue may skip stores)
             if (young >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
             else if (young == 38) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
             else if (young == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
