@@ -1727,7 +1727,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt128_kernel(GemmParams p) {
 // Four phases of 16 MFMAs over the same half-tile ring as gemm_nt256_kernel with TWO barriers per K-tile: after phase 2 (every
 // wave has read this ring's dY slots, which phases 3/4 restage) and after the counted wait of phase 4 (step s+1 has landed; every
 // wave has read this ring's X slots, which the next step restages).  Between them the waves drift by up to two phases, so one
-// wave's transposed reads overlap another's MFMAs.  The operand half-tiles are [64 m][128 cols]
+// wave's transposed reads overlap another's MFMAs; since round 2 every wave also issues its own reads one half-phase ahead of the
+// MFMAs that use them (inline asm, hand-counted waits - see the loop).  The operand half-tiles are [64 m][128 cols]
 // (256-byte rows) and every fragment is a pair of transposed LDS reads.  The reduction axis is the
 // long token axis M, split over workgroups so that tiles x splits ~ number of CUs; partial tiles are
 // added into dW with fp32 atomics issued as full 256-byte rows (staged through LDS).
