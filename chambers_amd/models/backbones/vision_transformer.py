@@ -8,9 +8,9 @@ get_weights()/set_weights().  Execution goes through the whole-model HIP engine 
 
 `pooling` ('cls' | 'avg' | 'max' | 'sum' | None), `feature_dim` (tanh head) and `include_top` follow :172-191,272-283.
 `DistilledVisionTransformer` / `DeiTS16` / `DeiTB16` (:295-400, :583-652) add the distillation token and its head.
-Not built here: the pretrained-weight
-download (`weights="imagenet21k+_224"` needs network + .h5); `weights` may be None or a path to an .npz of
-Keras-named arrays."""
+The pretrained-weight names, default sizes and the feature-layer rule follow :99-128; the download itself is not built
+(`weights="imagenet21k+_224"` needs network + .h5): such a name resolves to a local cache file (`_load_weights`), and
+`weights` may also be None or a path to an .npz of Keras-named arrays."""
 import os
 
 import numpy as np
@@ -25,8 +25,63 @@ from ...layers.core import Conv2D, Dense, Dropout, Reshape
 from ...layers.embedding import ConcatEmbedding, LearnedEmbedding1D
 from ...layers.transformer import Encoder
 
-_PRETRAINED_TAGS = {"imagenet21k_224", "imagenet21k+_224", "imagenet21k+_384", "imagenet_224_deit", "imagenet_384_deit",
-                    "imagenet_224_deit_distilled", "imagenet_384_deit_distilled"}
+# (model name -> `weights` name -> file suffix) of the reference's release table (vision_transformer.py:15-96).  The md5 hashes of
+# that table are not carried: this build never downloads - a pretrained file is looked up in a local cache directory only.
+_WEIGHT_SUFFIXES = {
+    "vits16": {"imagenet_224_deit": "imagenet_1000_224_deit"},
+    "vitb16": {"imagenet21k": "imagenet_21k_224", "imagenet21k+_224": "imagenet_21k_1000_224", "imagenet21k+_384": "imagenet_21k_1000_384",
+               "imagenet_224_deit": "imagenet_21k_1000_224_deit", "imagenet_384_deit": "imagenet_21k_1000_384_deit"},
+    "vitb32": {"imagenet21k": "imagenet_21k_224", "imagenet21k+_384": "imagenet_21k_1000_384"},
+    "vitl16": {"imagenet21k": "imagenet_21k_224", "imagenet21k+_224": "imagenet_21k_1000_224", "imagenet21k+_384": "imagenet_21k_1000_384"},
+    "vitl32": {"imagenet21k": "imagenet_21k_224", "imagenet21k+_384": "imagenet_21k_1000_384"},
+    "deits16": {"imagenet_224": "imagenet_1000_224"},
+    "deitb16": {"imagenet_224": "imagenet_1000_224", "imagenet_384": "imagenet_1000_384"},
+}
+
+
+def _are_weights_pretrained(weights, model_name):
+    """vision_transformer.py:99-100: a (zoo model, weights name) pair of the release table."""
+    return (model_name in _WEIGHT_SUFFIXES) and (weights in _WEIGHT_SUFFIXES[model_name])
+
+
+def _get_model_info(weights, model_name):
+    """vision_transformer.py:103-114: (default input size, has a pre-logits feature layer) from the file suffix."""
+    if _are_weights_pretrained(weights, model_name):
+        suffix = _WEIGHT_SUFFIXES[model_name][weights].replace("_deit", "")
+        return int(suffix.split("_")[-1]), ("21k" in suffix and "1000" not in suffix)
+    return 224, False
+
+
+def _check_pretrained_shape(input_shape, default_size, weights, model_name):
+    """vision_transformer.py:120-128."""
+    if input_shape is not None and _are_weights_pretrained(weights, model_name):
+        default_shape = (default_size, default_size, input_shape[-1])
+        if tuple(input_shape) != default_shape:
+            raise ValueError("Weights '{}' require `input_shape` to be {}.".format(weights, default_shape))
+
+
+def _weights_cache_dir():
+    return os.environ.get("CHB_WEIGHTS_DIR") or os.path.join(os.path.expanduser("~"), ".keras", "models")
+
+
+def _load_weights(model, weights, include_top):
+    """vision_transformer.py:149-169 without the download: a pretrained name resolves to `<model>_<suffix>[_no_top]` in the local
+    cache ($CHB_WEIGHTS_DIR, else ~/.keras/models - where keras `get_file` would have put it), as `.npz` of Keras-named arrays
+    (this image has no HDF5 reader: convert the release's `.h5` once with h5py elsewhere); any other string is a path."""
+    if _are_weights_pretrained(weights, model.name):
+        stem = model.name + "_" + _WEIGHT_SUFFIXES[model.name][weights] + ("" if include_top else "_no_top")
+        path = os.path.join(_weights_cache_dir(), stem + ".npz")
+        if not os.path.exists(path):
+            h5 = os.path.join(_weights_cache_dir(), stem + ".h5")
+            raise RuntimeError("pretrained weights %r of %s: the reference downloads %s.h5 from its GitHub release (vision_transformer.py:"
+                               "149-167); this build has no network path and no HDF5 reader - put %s.npz (Keras-named arrays) into %s%s, "
+                               "or pass weights=None / a path to such an .npz / use Model.load_timm_state_dict"
+                               % (weights, model.name, stem, stem, _weights_cache_dir(), " (found %s, not readable here)" % h5 if os.path.exists(h5) else ""))
+        model.load_weights(path)
+    elif weights is not None:
+        if not os.path.exists(str(weights)):
+            raise ValueError("weights file not found: %s" % (weights,))
+        model.load_weights(weights)
 
 
 def _obtain_input_shape(input_tensor, input_shape, default_size, min_size):
@@ -245,15 +300,20 @@ class Model(Layer):
 def VisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate=0.1, input_tensor=None, input_shape=None,
                       include_top=True, weights="imagenet21k+_224", pooling="cls", feature_dim=None, classes=1000,
                       classifier_activation=None, model_name=None):
-    if weights in _PRETRAINED_TAGS:
-        if feature_dim is not None:
-            raise ValueError("'weights' and 'feature_dim' are mutually exclusive.")
-        raise RuntimeError("pretrained weights %r are downloaded from GitHub releases by the reference (vision_transformer.py:149-167); "
-                           "this build has no network path — pass weights=None or a path to an .npz of Keras-named arrays" % (weights,))
+    weights_are_pretrained = _are_weights_pretrained(weights, model_name)
+    default_size, has_feature = _get_model_info(weights, model_name)
+    if weights_are_pretrained and feature_dim is not None:
+        raise ValueError("'weights' and 'feature_dim' are mutually exclusive.")
+    elif weights_are_pretrained and has_feature:
+        feature_dim = patch_dim
+        if include_top:
+            print("Warning: weights '{}' has no top. 'include_top' will be set to False.".format(weights))
+            include_top = False
+    _check_pretrained_shape(input_shape, default_size, weights, model_name)
     if classifier_activation not in (None, "linear", "softmax"):
         raise ValueError("classifier_activation must be None / 'linear' / 'softmax' (the loss kernel consumes logits); got %r"
                          % (classifier_activation,))
-    shape = _obtain_input_shape(input_tensor, input_shape, default_size=224, min_size=patch_size)
+    shape = _obtain_input_shape(input_tensor, input_shape, default_size=default_size, min_size=patch_size)
     cfg = E.ViTConfig(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate, image_size=shape[:2], classes=classes,
                       include_top=include_top, feature_dim=feature_dim, pooling="none" if pooling is None else pooling)
     tn = initializers.TruncatedNormal(stddev=0.02)
@@ -283,10 +343,7 @@ def VisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, 
         layers.append(head)
     model = Model(cfg, layers, name=model_name)
     model.classifier_activation = classifier_activation if include_top else None
-    if weights is not None:
-        if not os.path.exists(str(weights)):
-            raise ValueError("weights file not found: %s" % (weights,))
-        model.load_weights(weights)
+    _load_weights(model, weights, include_top)
     return model
 
 
@@ -297,16 +354,14 @@ def DistilledVisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads,
     so the sequence is [cls, dist, patches]) and a second head `predictions_dist` on the distillation token.  Outputs
     `[x_cls, x_dist]`, or their average when return_dist_token=False.  (The reference's default `pooling=None` would feed the
     whole sequence to the class head; its zoo entries pass "cls", and so must callers here.)"""
-    if weights in _PRETRAINED_TAGS or weights in ("imagenet_224", "imagenet_384"):
-        raise RuntimeError("pretrained weights %r are downloaded from GitHub releases by the reference (vision_transformer.py:149-167); "
-                           "this build has no network path — pass weights=None, an .npz of Keras-named arrays, or use "
-                           "Model.load_timm_state_dict" % (weights,))
+    default_size, _has_feature = _get_model_info(weights, model_name)
+    _check_pretrained_shape(input_shape, default_size, weights, model_name)
     if classifier_activation not in (None, "linear", "softmax"):
         raise ValueError("classifier_activation must be None / 'linear' / 'softmax'; got %r" % (classifier_activation,))
     if pooling is None:
         raise ValueError("pooling=None hands the whole token sequence to the class head in the reference (vision_transformer.py:373);"
                          " pass pooling='cls' (what DeiTS16 / DeiTB16 do) or 'avg' / 'max' / 'sum'")
-    shape = _obtain_input_shape(input_tensor, input_shape, default_size=224, min_size=patch_size)
+    shape = _obtain_input_shape(input_tensor, input_shape, default_size=default_size, min_size=patch_size)
     cfg = E.ViTConfig(patch_size, patch_dim, n_encoder_layers, n_heads, ff_dim, dropout_rate, image_size=shape[:2], classes=classes,
                       include_top=include_top, pooling=pooling, distilled=True, return_dist_token=return_dist_token)
     tn = initializers.TruncatedNormal(stddev=0.02)
@@ -331,10 +386,7 @@ def DistilledVisionTransformer(patch_size, patch_dim, n_encoder_layers, n_heads,
             layers.append(head)
     model = Model(cfg, layers, name=model_name)
     model.classifier_activation = classifier_activation if include_top else None
-    if weights is not None:
-        if not os.path.exists(str(weights)):
-            raise ValueError("weights file not found: %s" % (weights,))
-        model.load_weights(weights)
+    _load_weights(model, weights, include_top)
     return model
 
 
