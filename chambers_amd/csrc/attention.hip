@@ -1431,7 +1431,12 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
     const int algo = chb_option(CHB_OPT_ATTN_FWD_ALGO);
     // default for N <= 224: the whole-head kernel (K / V in LDS once, online softmax, two hashes per four keys, keep bits saved for
     // the backward).  CHB_ATTN_FWD_ALGO = 1 | 2 forces the resident (N <= 224) | streaming kernel: the parity tests cross-check.
-    if (N <= 224 && algo != 1 && algo != 2) {
+    // Keep bits asked for (drop_bits with dropout on): only the whole-head kernel writes them, so it runs whatever the A/B switch
+    // says - a backward that tested bits nobody wrote would silently use another mask than the forward.  Beyond 224 tokens no
+    // kernel writes them: refused.
+    const bool want_bits = drop_bits != nullptr && thr != 0u;
+    if (want_bits && N > 224) return CHB_EUNSUPPORTED;
+    if (N <= 224 && (want_bits || (algo != 1 && algo != 2))) {
         const int nkt = (N + 15) >> 4;
         const int nw = (nkt + 1) >> 1;
         const size_t lds = (size_t)2 * nkt * 16 * HD * sizeof(bf16_t);

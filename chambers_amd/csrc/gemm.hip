@@ -744,12 +744,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
     // Tile queue (K >= 8 K-tiles): a workgroup's first tile is its static one, every later tile is the next ticket of its XCD's
     // counter.  A workgroup that starts late (its CU was held by another stream's kernel - a collective) then simply draws fewer
     // tickets: the launch loses that CU's share of the time it was away, not a whole static tile share at the end.
-    // Tile j + 1 is claimed while tile j is young: wave 0 draws the ticket at the end of K-step k0 = slot & 3, hands it over
-    // in K-step k0 + 1 (the atomic has returned by that step's vmcnt(0)), every wave picks it up in K-step k0 + 2 - the staging
-    // streams need it from K-step ntk - 2 on.
+    // Tile j + 1 is claimed while tile j is young: wave 0 draws the ticket behind the barrier of K-step k0 = slot & 3; the vmcnt(0) of
+    // K-step k0 + 1 covers its return, wave 0 then hands it over through LDS in front of that step's barrier and every wave picks it
+    // up behind it - the staging streams need it from K-step ntk - 2 on.
     w.dyn = (p.queue_slot >= 0 && w.ntk >= 8) ? 1 : 0;
     const int q_k0 = w.slot & 3;      // the XCD's 32 workgroups run in step: spread their draws over four K-steps
     int* q_ctr = &g_tile_ctr[w.dyn ? p.queue_slot : 0][blockIdx.x & 7];
+    int* q_lds = reinterpret_cast<int*>(smem + 2 * 4 * 8192);
     int q_ticket = 0;
 
     // lane-constant byte offsets of the two LDS-DMA instructions a wave issues per half-tile (row 64 j + 8 wave + lane / 8)
@@ -847,17 +848,34 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
         // all of step s+1 (A issued in phase 1 of this step, B after the previous step's barrier) has landed when the barrier opens
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PHASE(4)       // vmcnt(0)
+        if (w.dyn && cc.kt == q_k0 + 1 && wave == 0) {     // scalar branch
+            // The ticket drawn behind the previous step's barrier has returned (that vmcnt(0) covers it).  The asm statement marks
+            // the first point at which the register may be looked at: tools/check_ticket_isa.py verifies on the built code that no
+            // instruction touches it between the atomic and a vmcnt wait.
+            asm volatile("" : "+v"(q_ticket));
+            if (lane == 0) {
+                // tickets 0 .. cnt-1 are drawn per XCD and launch (one per tile started): ticket t is tile stride + t of the
+                // XCD's list, and whoever holds the last one leaves the counter clean for the slot's next launch
+                *q_lds = w.stride + q_ticket;
+                if (q_ticket == w.cnt - 1) __hip_atomic_store(q_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the word is in LDS before this wave reaches the barrier
+        }
         __builtin_amdgcn_s_barrier();          // every wave has consumed this ring's A and B half-tiles; step s+1 has landed
         __builtin_amdgcn_sched_barrier(0);
         PHASE(5)       // barrier
         if (w.dyn) {
-            // The ticket is drawn right behind this step's vmcnt(0): its round trip has a whole K-step before the next vmcnt(0)
+            // The next ticket is drawn right behind this step's vmcnt(0): its round trip has a whole K-step before the next vmcnt(0)
             // has to cover it.  (Inline asm: hipcc's atomicAdd aggregates over the wave and reads the result back at once - an
             // s_waitcnt vmcnt(0) right behind the atomic, which stalled wave 0 and with it the workgroup for the round trip; an
             // asm result is outside its bookkeeping.  Lane 0 only, in-place operand.)  The hand-off to the other waves goes
             // through a word of wave 0's epilogue scratch, idle during the K-loop: global stores / coherent loads would each
             // sit in a K-step's vmcnt(0) for longer than the LDS-DMA loads that wait is there for (measured: -2...-3 % per GEMM).
-            int* q_lds = reinterpret_cast<int*>(smem + 2 * 4 * 8192);
+            if (cc.kt == q_k0 + 1) {               // wave 0's LDS write is one barrier old
+                const int nxt = __builtin_amdgcn_readfirstlane(*q_lds);
+                const int q = (cc.j + 1) & 3;
+                if (q == 0) w.li_tab[0] = nxt; else if (q == 1) w.li_tab[1] = nxt; else if (q == 2) w.li_tab[2] = nxt; else w.li_tab[3] = nxt;
+            }
             if (cc.kt == q_k0 && wave == 0) {      // scalar branch
                 q_ticket = 1;
                 uint64_t save;
@@ -865,17 +883,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmParams p) {
                              : [t] "+v"(q_ticket), [sv] "=&s"(save)
                              : [off] "v"(0), [ptr] "s"(q_ctr)
                              : "memory");
-            }
-            if (cc.kt == q_k0 + 1 && wave == 0 && lane == 0) {
-                // tickets 0 .. cnt-1 are drawn per XCD and launch (one per tile started): ticket t is tile stride + t of the
-                // XCD's list, and whoever holds the last one leaves the counter clean for the slot's next launch
-                *q_lds = w.stride + q_ticket;
-                if (q_ticket == w.cnt - 1) __hip_atomic_store(q_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (cc.kt == q_k0 + 2) {               // wave 0's LDS write is one barrier old
-                const int nxt = __builtin_amdgcn_readfirstlane(*q_lds);
-                const int q = (cc.j + 1) & 3;
-                if (q == 0) w.li_tab[0] = nxt; else if (q == 1) w.li_tab[1] = nxt; else if (q == 2) w.li_tab[2] = nxt; else w.li_tab[3] = nxt;
             }
         }
         if (cb.valid) {                        // this ring's B slots are free now: step s+2 goes into them
@@ -1118,6 +1125,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256sp_kernel(GemmParams p) {
         if (cc.kt == 0) { PHASE(3) } else if (cc.kt == 1) { PHASE(2) } else if (cc.kt == 2) { PHASE(6) } else { PHASE(4) }
 #endif
         if (w.dyn && cc.kt == q_k0 + 1 && wave == 0) {     // scalar branch
+            asm volatile("" : "+v"(q_ticket));             // first look at the ticket register: behind the counted wait above (tools/check_ticket_isa.py)
             if (lane == 0) {
                 // tickets 0 .. cnt-1 are drawn per XCD and launch (one per tile started): ticket t is tile stride + t of the XCD's
                 // list, and whoever holds the last one leaves the counter clean for the slot's next launch

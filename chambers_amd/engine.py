@@ -407,7 +407,8 @@ class _SideRing:
 
 # ---------------------------------------------------------------------------------------------
 class ViTEngine:
-    def __init__(self, cfg, batch_size, device=None, training=True, seed=0, decay_fn=None, process_group=None, overlap_wgrad=None):
+    def __init__(self, cfg, batch_size, device=None, training=True, seed=0, decay_fn=None, process_group=None, overlap_wgrad=None,
+                 pad_m=None):
         if not torch.cuda.is_available():
             raise RuntimeError("ViTEngine needs an MI355X (torch.cuda is not available); there is no CPU fallback")
         self.cfg, self.B, self.training, self.seed = cfg, int(batch_size), bool(training), int(seed)
@@ -431,11 +432,10 @@ class ViTEngine:
             self.Vo = torch.zeros(nflat, dtype=f32, device=dev)
             self._upload_decay_flags()
             self.reducer = GradBucketReducer(self.G, self.buckets, process_group)
-            if self.reducer.active:
-                # a collective's kernel takes CUs from whatever launch it lands on: with the tile queue the persistent GEMM's
-                # late workgroups draw fewer tiles instead of stretching the launch by the collective's duration (within
-                # +-1 % per GEMM when nothing competes; off for single-GPU runs; tools/rccl_contention.py)
-                _lib.set_option("GEMM_TILE_QUEUE", 1)
+            # The persistent GEMMs' tile queue (CHB_GEMM_TILE_QUEUE=1: late workgroups draw fewer tiles instead of stretching the
+            # launch by a co-running collective's duration; tools/rccl_contention.py) stays OPT-IN: the engine does not
+            # switch it on by itself, not even for data-parallel runs, until a real multi-GPU RCCL run has confirmed bit-equal
+            # output and clean counters there.
             self._g_clean = True        # G holds zeros (allocation, or the last AdamW launch cleared it behind its read)
         mats = [s for s in self.specs if s.matrix]
         desc = np.array([[s.offset, s.offset, s.shape[0], s.shape[1]] for s in mats], dtype=np.int64)
@@ -444,6 +444,7 @@ class ViTEngine:
         self.ct_tiles = max(((s.shape[0] + 63) // 64) * ((s.shape[1] + 63) // 64) for s in mats)
         self.opt_step = 0
         self._overlap_arg = overlap_wgrad
+        self._pad_arg = pad_m
         self._alloc_activations()
 
     def _upload_decay_flags(self):
@@ -496,6 +497,12 @@ class ViTEngine:
         return internal_to_keras(iw, self.cfg)
 
     def export_keras_grads(self):
+        """Gradients of the last backward in the Keras layout.  adamw_step(zero_grad=True) - the default, and what train_step /
+        Model.train_step / optimizer.apply run - clears the gradient buffer behind its read: asking for gradients after it is an
+        error, not a dictionary of zeros (call this between backward() and the optimizer step, or step with zero_grad=False)."""
+        if self._g_clean:
+            raise RuntimeError("no gradients to export: the buffer was cleared by adamw_step(zero_grad=True) (or no backward has run); "
+                               "export between backward() and the optimizer step, or pass zero_grad=False")
         host = self.G.detach().cpu().numpy()
         iw = {s.name: host[s.offset:s.offset + s.size].reshape(s.shape).copy() for s in self.specs}
         return internal_to_keras(iw, self.cfg)
@@ -511,6 +518,18 @@ class ViTEngine:
         d, ff, n = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens
         self.M = B * n
         self.Mp = _round_up(self.M, 256)
+        # Rows the block GEMMs (forward projections and dgrad) are LAUNCHED over.  Every token matrix has Mp rows, so a ragged
+        # M = batch x tokens (config 5: 128 x 577 = 288.5 tiles) can run as Mp = full 256-row tiles and take the pipelined full-tile
+        # kernel instead of the lockstep one with clamped staging and a guarded epilogue (5-15 % slower).  What makes that safe:
+        #  * forward pad rows hold junk (bias, gelu(bias), ...: finite) that nothing reads: LayerNorm, attention, pooling, the loss and
+        #    every reduction over tokens run over the true M (or over batch elements);
+        #  * backward pad rows are exactly ZERO and stay zero: the gradient buffers start as zeros, LayerNorm / attention / dropout
+        #    backward write the true M rows only, and a dgrad GEMM maps zero rows to zero rows (no bias in backward; the gelu'-multiply
+        #    multiplies 0 by a finite saved value), so the fused column sums and the weight-gradient GEMMs (which already reduce over
+        #    Mp rows) add nothing for them.
+        # Small problems (below the persistent kernel's threshold) keep the true M.  CHB_PAD_M=0 / pad_m=False: launch over M.
+        pad = bool(int(os.environ.get("CHB_PAD_M", "1"))) if self._pad_arg is None else bool(self._pad_arg)
+        self.Mg = self.Mp if (pad and self.M >= 2048) else self.M
         self.Bp = _round_up(B, 64)
         self.Mpatch = B * cfg.n_patches
         self.Mpatch_p = _round_up(self.Mpatch, 64)
@@ -628,20 +647,20 @@ class ViTEngine:
     def block_forward(self, l, x_in, x_out, a, training):
         cfg = self.cfg
         rate, key = self._keys(training)
-        d, M = cfg.patch_dim, self.M
+        d, M, Mg = cfg.patch_dim, self.M, self.Mg
         pre = "encoder/layer_%d/" % l
         K.layernorm_fwd(x_in, d, self.p(pre + "norm1/gamma"), self.p(pre + "norm1/beta"), a["h1"], a["mean1"], a["rstd1"], M, d,
                         cfg.norm_epsilon)
-        K.gemm_nt(a["h1"], self.wbt(pre + "qkv/kernel"), a["qkv"], m=M, bias=self.p(pre + "qkv/bias"))
+        K.gemm_nt(a["h1"], self.wbt(pre + "qkv/kernel"), a["qkv"], m=Mg, bias=self.p(pre + "qkv/bias"))
         K.attention_fwd(a["qkv"], a["o"], a["lse"], self.B, cfg.n_tokens, cfg.n_heads, cfg.head_dim, rate, key(rng.site_attn(l)),
                         drop_bits=a["drop_bits"] if rate else None)
-        K.gemm_nt(a["o"], self.wbt(pre + "proj/kernel"), a["xmid"], m=M, bias=self.p(pre + "proj/bias"), epilogue=K.EPI_RESID,
+        K.gemm_nt(a["o"], self.wbt(pre + "proj/kernel"), a["xmid"], m=Mg, bias=self.p(pre + "proj/bias"), epilogue=K.EPI_RESID,
                   resid=x_in, drop_rate=rate, drop_key=key(rng.site_proj(l)))
         K.layernorm_fwd(a["xmid"], d, self.p(pre + "norm2/gamma"), self.p(pre + "norm2/beta"), a["h2"], a["mean2"], a["rstd2"], M, d,
                         cfg.norm_epsilon)
-        K.gemm_nt(a["h2"], self.wbt(pre + "dense1/kernel"), a["u"], m=M, bias=self.p(pre + "dense1/bias"), epilogue=K.EPI_GELU,
+        K.gemm_nt(a["h2"], self.wbt(pre + "dense1/kernel"), a["u"], m=Mg, bias=self.p(pre + "dense1/bias"), epilogue=K.EPI_GELU,
                   aux=a["a1"])
-        K.gemm_nt(a["u"], self.wbt(pre + "dense2/kernel"), x_out, m=M, bias=self.p(pre + "dense2/bias"), epilogue=K.EPI_RESID,
+        K.gemm_nt(a["u"], self.wbt(pre + "dense2/kernel"), x_out, m=Mg, bias=self.p(pre + "dense2/bias"), epilogue=K.EPI_RESID,
                   resid=a["xmid"], drop_rate=rate, drop_key=key(rng.site_mlp(l)))
 
     def forward(self, images_u8, training=None, prepatched=False, augment=None):
@@ -734,7 +753,7 @@ class ViTEngine:
         (include_top=False: pooled embedding or tanh feature as output) takes d(loss)/d(output) fp32 [B, F] as `doutput`."""
         cfg = self.cfg
         rate, key = self._keys(True)
-        d, ff, n, M, Mp = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens, self.M, self.Mp
+        d, ff, n, M, Mp, Mg = cfg.patch_dim, cfg.ff_dim, cfg.n_tokens, self.M, self.Mp, self.Mg
         L = cfg.n_encoder_layers
         F = cfg.feature_dim
         # a collective of the previous backward may still be reading / writing slices of G (backward called twice without an
@@ -816,16 +835,16 @@ class ViTEngine:
             # MLP branch (self.dz = dropout-backward of dx at site_mlp(l))
             wgrad(a["u"], "dz", pre + "dense2/kernel")
             dz = self.dz
-            K.gemm_nt(dz, self.wb(pre + "dense2/kernel"), nxt("da1"), m=M, epilogue=K.EPI_DGELU, aux=a["a1"],
+            K.gemm_nt(dz, self.wb(pre + "dense2/kernel"), nxt("da1"), m=Mg, epilogue=K.EPI_DGELU, aux=a["a1"],
                       colsum=self.g(pre + "dense1/bias"))           # bias gradient of dense1 fused into the epilogue
             wgrad(a["h2"], "da1", pre + "dense1/kernel")
-            K.gemm_nt(self.da1, self.wb(pre + "dense1/kernel"), self.dh, m=M)
+            K.gemm_nt(self.da1, self.wb(pre + "dense1/kernel"), self.dh, m=Mg)
             K.layernorm_bwd(self.dh, a["xmid"], d, a["mean2"], a["rstd2"], self.p(pre + "norm2/gamma"), self.dx, d, True,
                             self.g(pre + "norm2/gamma"), self.g(pre + "norm2/beta"), M, d, dz=nxt("dz"),
                             dz_colsum=self.g(pre + "proj/bias"), drop_rate=rate, drop_key=key(rng.site_proj(l)))
             # attention branch (self.dz = dropout-backward of dx at site_proj(l))
             wgrad(a["o"], "dz", pre + "proj/kernel")
-            K.gemm_nt(self.dz, self.wb(pre + "proj/kernel"), self.do, m=M)
+            K.gemm_nt(self.dz, self.wb(pre + "proj/kernel"), self.do, m=Mg)
             # this block's MLP / projection gradients and the previous block's QKV gradients are final and adjacent in the flat
             # buffer: one all-reduce, started beside the attention backward
             self.reducer.bucket_ready(2 * (L - l) - 1)
@@ -838,7 +857,7 @@ class ViTEngine:
             # launch instead of a 0.09 ms pass over dqkv (attention_bwd can also fuse it via dbias=, but its four extra
             # accumulators and the cross-wave fold make the 128-register kernel spill: 0.99 ms against 0.69)
             wgrad(a["h1"], "dqkv", pre + "qkv/kernel", colsum=self.g(pre + "qkv/bias"))
-            K.gemm_nt(self.dqkv, self.wb(pre + "qkv/kernel"), self.dh, m=M)
+            K.gemm_nt(self.dqkv, self.wb(pre + "qkv/kernel"), self.dh, m=Mg)
             if l > 0:
                 K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
                                 self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d, dz=nxt("dz"),

@@ -109,7 +109,7 @@ class Model(Layer):
     def __init__(self, cfg, layers, name=None):
         super().__init__(name=name)
         self.cfg = cfg
-        self.layers = layers
+        self._layers = layers
         self.built = True
         self._engines = {}
         self._loaded_version = {}
@@ -117,10 +117,16 @@ class Model(Layer):
         self._decay_key = {}        # engine key -> id of the optimizer whose decay flags it carries
 
     def _sublayers(self):
-        return list(self.layers)
+        return list(self._layers)
+
+    @property
+    def layers(self):
+        self._sync()
+        return self._layers
 
     def get_layer(self, name):
-        for layer in self.layers:
+        self._sync()          # a reader of a sub-layer's variables sees the trained weights, like keras after fit
+        for layer in self._layers:
             if layer.name == name:
                 return layer
         raise ValueError("No such layer: " + name)
@@ -281,9 +287,13 @@ class Model(Layer):
         if not self.cfg.include_top:
             raise ValueError("train_step needs the classification top (include_top=True)")
         eng = self.engine(key[0], training=True)
-        if self._decay_key.get(key) != id(optimizer):
+        # keyed on the filter lists themselves, not on the optimizer object: mutating decay_include / decay_exclude between steps
+        # takes effect (optimizers.py:169-181 reads them at every apply)
+        flt = (None if optimizer.decay_include is None else tuple(optimizer.decay_include),
+               None if optimizer.decay_exclude is None else tuple(optimizer.decay_exclude))
+        if self._decay_key.get(key) != flt:
             eng.set_decay_fn(optimizer.decay_fn(self.cfg))
-            self._decay_key[key] = id(optimizer)
+            self._decay_key[key] = flt
         eng.forward(images_u8, training=True)
         loss = eng.loss(labels)
         eng.backward()

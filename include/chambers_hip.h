@@ -67,7 +67,7 @@ extern "C" {
 #define CHB_OUT_F32 1
 
 /* ---------------------------------------------------------------- library info */
-int chb_version(void);            /* ABI version, currently 1 */
+int chb_version(void);            /* ABI version, currently 3 (round 3) */
 const char* chb_build_arch(void); /* "gfx950" */
 
 /* ---------------------------------------------------------------- augmentation (uint8 NHWC) */
@@ -172,7 +172,9 @@ int chb_layernorm_bwd(const void* dy_bf16, const float* x, int64_t x_stride, con
  * drop_bits (optional, uint32 [B*H*N*8], N <= 224, drop_rate > 0): the forward writes the keep bits of the mask it applied
  * (word ((bh*N + q)*4 + g)*2 + (t >> 3), bit 16*(r&1) + 8*(r>>1) + (t & 7) for key 16*t + 4*g + r); handed to chb_attention_bwd, the
  * backward tests bits instead of re-hashing (keras Dropout keeps its mask for the backward pass likewise).  NULL: nothing is
- * written / the backward regenerates the mask from the element index.  Same results either way. */
+ * written / the backward regenerates the mask from the element index.  Same results either way.  With drop_bits and
+ * drop_rate > 0 the forward ALWAYS runs the kernel that writes them (the ATTN_FWD_ALGO switch is ignored for that call);
+ * N > 224 with drop_bits returns CHB_EUNSUPPORTED (no kernel writes bits there). */
 int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int hd, float drop_rate,
                       uint32_t drop_key, uint32_t* drop_bits, void* stream);
 /* dbias_qkv (fp32 [3*H*hd], optional): += column sums of dqkv (bias gradient of the fused QKV projection), taken from the

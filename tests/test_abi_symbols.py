@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), "libchambers_hip.so lacks %s" % name
     typed = _lib.load()
-    assert typed.chb_version() == 2 and typed.chb_build_arch() == b"gfx950"
+    assert typed.chb_version() == 3 and typed.chb_build_arch() == b"gfx950"
     # every declared entry has a ctypes prototype (and vice versa)
     assert set(_declared()) == set(_lib.PROTOTYPES) | set(_lib.INFO_SYMBOLS)
 
@@ -68,3 +68,20 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_tile_queue_ticket_register_is_untouched_until_its_wait():
+    """the tile queue's returning atomic lands in a VGPR hipcc believes defined at once.  On the BUILT code object no
+    instruction may name that register between the atomic and a vmcnt wait (tools/check_ticket_isa.py), and the queue is opt-in."""
+    import importlib.util
+    import shutil
+    obj = os.path.join(ROOT, "chambers_amd", "csrc", "gemm.o")
+    if not os.path.exists(obj) or not shutil.which("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the built gemm.o and the ROCm llvm tools")
+    spec = importlib.util.spec_from_file_location("check_ticket_isa", os.path.join(ROOT, "tools", "check_ticket_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    found, problems = mod.check(mod.device_disassembly(obj))
+    assert len(found) >= 20 and not problems, problems[:5]
+    src = open(os.path.join(ROOT, "chambers_amd", "engine.py")).read()
+    assert 'set_option("GEMM_TILE_QUEUE"' not in src          # the engine never forces the queue on

@@ -460,3 +460,53 @@ def test_training_steps_track_huggingface_vit_with_torch_adamw():
     # measured: ours 2.5073 2.4218 2.3670 2.3328 2.3124 vs 2.5075 2.4211 2.3661 2.3320 2.3115 (worst 3.9e-4); bound = x 1.5
     fp_check("HIP engine vs transformers ViT + torch AdamW | worst per-step loss over 5 steps", worst, 6e-4)
     assert ours[-1] < ours[0] - 0.05 and theirs[-1] < theirs[0] - 0.05
+
+
+def test_ragged_token_count_runs_on_padded_tiles_and_pad_rows_stay_zero():
+    """M = batch x tokens that is not a multiple of 256 (config 5's situation: 128 x 577) is LAUNCHED over Mp = full 256-row tiles so
+    the block GEMMs take the full-tile kernel.  Invariants: (a) nothing observable changes - logits, loss, every gradient and the
+    weights after AdamW are bit-identical to the engine launched over the true M (pad_m=False); (b) after backward every pad row of
+    every gradient-side token matrix is exactly zero (so column sums and weight-gradient GEMMs over Mp rows add nothing);
+    (c) reductions over tokens used the true M (the LayerNorm / bias gradients are part of (a))."""
+    from chambers_amd.engine import ViTEngine
+    cfg = _cfg(patch_dim=256, n_heads=4, ff_dim=512, image_size=(64, 64))      # 17 tokens; widths multiples of 256: the full-tile kernel applies
+    bsz, seed = 130, 5                                                          # M = 2210 -> Mp = 2304 (8.63 -> 9 row tiles)
+    engs = {}
+    kw = images = labels = None
+    for pad in (True, False):
+        from chambers_amd.engine import init_keras_weights
+        if kw is None:
+            eng, kw, images, labels = _setup(cfg, bsz, training=True, seed=seed)
+            eng = None
+        e = ViTEngine(cfg, bsz, training=True, seed=seed, pad_m=pad)
+        e.load_keras_weights(kw)
+        engs[pad] = e
+    assert engs[True].Mg == engs[True].Mp == 2304 and engs[False].Mg == engs[False].M == 2210
+    out = {}
+    for pad, e in engs.items():
+        logits = e.forward(torch.as_tensor(images, device="cuda"), training=True).clone()
+        loss = e.loss(torch.as_tensor(labels).cuda()).clone()
+        e.backward()
+        grads = e.export_keras_grads()
+        if pad:
+            M = e.M
+            for name in ("dz", "da1", "dh", "do", "dqkv", "dx"):
+                t = getattr(e, name)
+                assert t.shape[0] == e.Mp and not bool(t[M:].any()), "pad rows of %s are not zero after backward" % name
+            for a in e.acts:
+                for name in ("h1", "o", "h2"):                      # written over the true M only: still the zeros they were allocated as
+                    assert not bool(a[name][M:].any()), name
+                assert torch.isfinite(a["u"][M:].float()).all() and torch.isfinite(a["a1"][M:].float()).all()
+        e.adamw_step(learning_rate=1e-3, weight_decay=0.05)
+        out[pad] = (logits.cpu(), loss.cpu(), grads, e.export_keras_weights())
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    for k in out[True][2]:
+        np.testing.assert_array_equal(out[True][2][k], out[False][2][k], err_msg="gradient " + k)
+        np.testing.assert_array_equal(out[True][3][k], out[False][3][k], err_msg="weights after AdamW " + k)
+    # a second step on the padded engine: junk in forward pad rows has been through a whole step and is still harmless
+    e = engs[True]
+    e.forward(torch.as_tensor(images, device="cuda"), training=True)
+    l2 = e.loss(torch.as_tensor(labels).cuda())
+    assert torch.isfinite(l2).all()
+    e.backward()
+    assert not bool(e.dqkv[e.M:].any()) and not bool(e.da1[e.M:].any())

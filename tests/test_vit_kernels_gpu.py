@@ -542,7 +542,7 @@ def test_attention_fwd_bwd(bsz, n, h, rate, variant):
     from chambers_amd import kernels as K
     d = h * 64
     key = 0x1234567
-    bits = K.attention_drop_bits(bsz, n, h) if variant == "lean_bits" else None
+    bits = K.attention_drop_bits(bsz, n, h) if (variant == "lean_bits" and n <= 224) else None     # no kernel writes bits beyond 224 tokens
     if bits is not None:
         bits.fill_(-1)
     qkv = bf(torch.randn(bsz * n, 3 * d, generator=g(40)))
@@ -633,6 +633,52 @@ def test_attention_fwd_streaming_matches_resident(bsz, n, h, rate, monkeypatch):
     assert torch.allclose(l1, l2, rtol=1e-6, atol=1e-5)
     assert rel_l2(o2, o1) < 4e-3
     assert torch.equal(o1 == 0, o2 == 0) or rate == 0.0   # identical keep mask (an all-dropped row is zero in both)
+
+
+@pytest.mark.parametrize("bsz,n,h", [(2, 197, 3), (3, 50, 2), (1, 224, 1)])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_attention_keep_bits_with_a_forced_forward_algo(bsz, n, h, algo):
+    """only the whole-head forward writes the keep bits.  With ATTN_FWD_ALGO forced to the resident (1) or streaming (2)
+    kernel a call that hands in drop_bits must still come back with the bits of the mask it applied: the backward that tests them
+    then equals the backward that re-hashes the mask, bit for bit, and the bits equal the mask definition."""
+    from chambers_amd import _lib, kernels as K
+    d, rate, key = h * 64, 0.1, 0x2468ace
+    qkv = bf(torch.randn(bsz * n, 3 * d, generator=g(47))).cuda()
+    do = bf(torch.randn(bsz * n, d, generator=g(48))).cuda()
+    o = torch.empty(bsz * n, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(bsz * h * n, dtype=torch.float32, device="cuda")
+    bits = K.attention_drop_bits(bsz, n, h)
+    bits.fill_(0x5a5a5a5a)                      # stale content: a forward that ignored the pointer would leave it
+    try:
+        _lib.set_option("ATTN_FWD_ALGO", algo)
+        K.attention_fwd(qkv, o, lse, bsz, n, h, 64, rate, key, drop_bits=bits)
+    finally:
+        _lib.set_option("ATTN_FWD_ALGO", 0)
+    o0 = torch.empty_like(o)
+    lse0 = torch.empty_like(lse)
+    K.attention_fwd(qkv, o0, lse0, bsz, n, h, 64, rate, key)           # the default route without bits: same output
+    assert torch.equal(o, o0) and torch.equal(lse, lse0)
+    keep = rng_ref.attn_keep_mask((bsz, h, n, n), key, rate)
+    w = bits.cpu().numpy().view(np.uint32).reshape(bsz, h, n, 4, 2)
+    kk = np.arange(n)
+    got = (w[..., (kk >> 2) & 3, kk >> 7] >> (16 * (kk & 1) + 8 * ((kk >> 1) & 1) + ((kk >> 4) & 7)).astype(np.uint32)) & 1
+    np.testing.assert_array_equal(got.astype(bool), keep)
+    d_bits = torch.zeros(bsz * n, 3 * d, dtype=torch.bfloat16, device="cuda")
+    d_hash = torch.zeros_like(d_bits)
+    K.attention_bwd(qkv, o, do, lse, d_bits, bsz, n, h, 64, rate, key, drop_bits=bits)
+    K.attention_bwd(qkv, o, do, lse, d_hash, bsz, n, h, 64, rate, key)
+    assert torch.equal(d_bits, d_hash)
+
+
+def test_attention_keep_bits_refused_beyond_224_tokens():
+    from chambers_amd import _lib, kernels as K
+    bsz, n, h = 1, 257, 1
+    qkv = torch.zeros(bsz * n, 3 * 64, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(bsz * n, 64, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(bsz * h * n, dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError):            # CHB_EUNSUPPORTED
+        K.attention_fwd(qkv, o, lse, bsz, n, h, 64, 0.1, 1, drop_bits=K.attention_drop_bits(bsz, n, h))
+    K.attention_fwd(qkv, o, lse, bsz, n, h, 64, 0.0, 1, drop_bits=K.attention_drop_bits(bsz, n, h))   # no dropout: nothing to write, accepted
 
 
 def test_attention_fwd_fp32_probabilities_tolerance():
