@@ -50,11 +50,22 @@ def default_device():
 
 class Variable:
     """A named weight; `value` is a torch tensor that the owning layer (or the training
-    engine, which may re-point it at a slice of its flat buffers) reads at call time."""
+    engine, which may re-point it at a slice of its flat buffers) reads at call time.  On the GPU a trainable variable is an
+    autograd leaf (requires_grad): the stand-alone layers' Functions (layers/autograd.py) leave its gradient in `value.grad`."""
 
-    def __init__(self, name, value):
+    def __init__(self, name, value, trainable=True):
         self.name = name
         self.value = value
+        self.trainable = bool(trainable)
+        if self.trainable and value.is_cuda and value.is_floating_point():
+            self.value.requires_grad_(True)
+
+    @property
+    def grad(self):
+        return self.value.grad
+
+    def zero_grad(self):
+        self.value.grad = None
 
     @property
     def shape(self):
@@ -67,7 +78,8 @@ class Variable:
         array = np.asarray(array)
         if tuple(array.shape) != self.shape:
             raise ValueError("Layer weight shape %s not compatible with provided weight shape %s" % (self.shape, tuple(array.shape)))
-        self.value.copy_(torch.as_tensor(array, dtype=self.value.dtype))
+        with torch.no_grad():
+            self.value.copy_(torch.as_tensor(array, dtype=self.value.dtype))
 
 
 class InputSpec:
@@ -98,7 +110,7 @@ class Layer:
     def add_weight(self, name, shape, initializer=None, dtype=None):
         from . import initializers
         value = initializers.get(initializer)(tuple(int(s) for s in shape))
-        var = Variable(self.name + "/" + name + ":0", torch.as_tensor(value, dtype=torch.float32).to(default_device()))
+        var = Variable(self.name + "/" + name + ":0", torch.as_tensor(value, dtype=torch.float32).to(default_device()), trainable=self.trainable)
         self._weights.append(var)
         return var
 

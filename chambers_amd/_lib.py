@@ -75,6 +75,12 @@ PROTOTYPES = {
     "chb_copy_rows": [P, c_int64, P, c_int64, c_int64, c_int64, P],
     "chb_softmax_f32": [P, c_int64, P, c_int64, c_int, c_int, P],
     "chb_set_option": [ctypes.c_char_p, c_int],
+    "chb_gelu_f32": [P, P, P, c_int64, c_int, P],
+    "chb_mul_f32": [P, P, P, c_int64, P],
+    "chb_scale_by_bf16": [P, c_int, P, P, c_int64, P],
+    "chb_dropout_f32": [P, P, c_int64, c_float, ctypes.c_uint32, P],
+    "chb_add_rows_f32": [P, P, P, c_int64, c_int64, P],
+    "chb_sum_rows_f32": [P, c_int64, c_int64, c_int64, P, P],
 }
 INFO_SYMBOLS = ["chb_version", "chb_build_arch"]
 

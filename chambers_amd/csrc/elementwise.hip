@@ -307,6 +307,64 @@ __global__ void __launch_bounds__(256) tanh_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---- trainable stand-alone layers (round 3): the pieces torch.autograd.Function wrappers of chambers_amd/layers need that the
+// whole-model engine has fused elsewhere - stand-alone GELU (activations.py:5-56) and its derivative, element-wise products for
+// their backward, Dropout as a layer (flat element index, the chb_dropout_mask definition), the positional-table add with its
+// batch reduction (layers/embedding.py:156-182) and the strided batch sum of ConcatEmbedding's backward (:218-261).
+__global__ void __launch_bounds__(256) gelu_f32_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ d, int64_t n,
+                                                       int approximate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float yy, dd;
+        if (approximate) {      // activations.py:30-44: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+            const float c = 0.7978845608028654f, k = 0.044715f;
+            const float t = tanhf(c * (v + k * v * v * v));
+            yy = 0.5f * v * (1.0f + t);
+            dd = 0.5f * (1.0f + t) + 0.5f * v * (1.0f - t * t) * c * (1.0f + 3.0f * k * v * v);
+        } else {
+            gelu_both(v, yy, dd);
+        }
+        y[i] = yy;
+        if (d) d[i] = dd;
+    }
+}
+
+__global__ void __launch_bounds__(256) mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+
+// out_bf16 = bf16(dy * aux): the backward of a Dense layer with the fused GELU epilogue (aux = the saved bf16 gelu'), one rounding -
+// what the engine's gelu'-multiply GEMM epilogue does to its fp32 accumulator
+template <bool DY_BF16>
+__global__ void __launch_bounds__(256) scale_by_bf16_kernel(const void* __restrict__ dy, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out,
+                                                            int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = DY_BF16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(dy)[i]) : reinterpret_cast<const float*>(dy)[i];
+        out[i] = f32_to_bf16(g * bf16_to_f32(aux[i]));
+    }
+}
+
+__global__ void __launch_bounds__(256) dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float scale, uint32_t thr,
+                                                          uint32_t key) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = chb_keep((uint64_t)i, key, thr) ? x[i] * scale : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) add_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ table, float* __restrict__ out,
+                                                           int64_t n, int64_t period) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i] + table[i % period];
+}
+
+// out[c] = sum over r < rows of x[r * row_stride + c], c < cols (one thread per column: consecutive threads read consecutive addresses)
+__global__ void __launch_bounds__(256) sum_rows_f32_kernel(const float* __restrict__ x, int64_t row_stride, int64_t rows, int64_t cols,
+                                                           float* __restrict__ out) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        for (int64_t r = 0; r < rows; ++r) acc += x[r * row_stride + c];
+        out[c] = acc;
+    }
+}
+
 }  // namespace
 
 // ---- small tensor utilities of the stand-alone layers (Dense(softmax), ConcatEmbedding, EncoderLayer's first residual, operand casts):
@@ -569,6 +627,60 @@ int chb_zero_f32(float* x, int64_t n, void* stream) {
     if (n == 0) return CHB_OK;
     if (((uintptr_t)x & 15) || (n & 3)) return CHB_EINVAL;
     hipLaunchKernelGGL(zero_f32_kernel, dim3(grid_for(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, x, n / 4);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_gelu_f32(const float* x, float* y, float* dydx, int64_t n, int approximate, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!x || !y || n < 0) return CHB_EINVAL;
+    hipLaunchKernelGGL(gelu_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, dydx, n, approximate);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_mul_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!a || !b || !out || n < 0) return CHB_EINVAL;
+    hipLaunchKernelGGL(mul_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_scale_by_bf16(const void* dy, int dy_dtype, const void* aux_bf16, void* out_bf16, int64_t n, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!dy || !aux_bf16 || !out_bf16 || n < 0) return CHB_EINVAL;
+    if (dy_dtype == CHB_OUT_BF16)
+        hipLaunchKernelGGL(scale_by_bf16_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, (const bf16_t*)aux_bf16, (bf16_t*)out_bf16, n);
+    else if (dy_dtype == CHB_OUT_F32)
+        hipLaunchKernelGGL(scale_by_bf16_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, (const bf16_t*)aux_bf16, (bf16_t*)out_bf16, n);
+    else
+        return CHB_EINVAL;
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_dropout_f32(const float* x, float* out, int64_t n, float rate, uint32_t key, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!x || !out || n < 0 || rate < 0.0f || rate >= 1.0f) return CHB_EINVAL;
+    hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, 1.0f / (1.0f - rate),
+                       rate > 0.0f ? chb_drop_threshold(rate) : 0u, key);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_add_rows_f32(const float* x, const float* table, float* out, int64_t n, int64_t period, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!x || !table || !out || n < 0 || period <= 0) return CHB_EINVAL;
+    hipLaunchKernelGGL(add_rows_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, table, out, n, period);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_sum_rows_f32(const float* x, int64_t row_stride, int64_t rows, int64_t cols, float* out, void* stream) {
+    if (cols == 0) return CHB_OK;
+    if (!x || !out || rows < 0 || cols < 0 || row_stride < cols) return CHB_EINVAL;
+    hipLaunchKernelGGL(sum_rows_f32_kernel, dim3(grid_for(cols)), dim3(256), 0, (hipStream_t)stream, x, row_stride, rows, cols, out);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

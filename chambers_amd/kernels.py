@@ -545,15 +545,22 @@ def add_f32(a, b, out=None):
     return out
 
 
-def cast_bf16(x):
-    """fp32 -> bf16 (round to nearest even), a bf16 tensor is returned as it is."""
-    if x.dtype == torch.bfloat16:
+def cast_bf16(x, out=None):
+    """fp32 -> bf16 (round to nearest even), a bf16 tensor is returned as it is.  out: a contiguous bf16 buffer with at least
+    x.numel() elements whose head receives the result (rows of a zero-padded operand); a bf16 x is copied there."""
+    if x.dtype == torch.bfloat16 and out is None:
         return x
-    _lib.require_gpu(x)
-    if x.dtype != torch.float32:
+    _lib.require_gpu(x, out)
+    if x.dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("cast_bf16 takes fp32 or bf16, got %s" % x.dtype)
     x = x.contiguous()
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    elif out.dtype != torch.bfloat16 or not out.is_contiguous() or out.numel() < x.numel():
+        raise ValueError("cast_bf16: out must be a contiguous bf16 buffer of at least x.numel() elements")
+    if x.dtype == torch.bfloat16:
+        out.view(-1)[:x.numel()].copy_(x.view(-1))          # same dtype: a device-to-device copy
+        return out
     _lib.call("chb_cast_f32_bf16", _lib.ptr(x), _lib.ptr(out), x.numel(), _s())
     return out
 
@@ -599,4 +606,76 @@ def softmax_rows(x):
     rows = x.numel() // max(cols, 1)
     out = torch.empty_like(x)
     _lib.call("chb_softmax_f32", _lib.ptr(x), cols, _lib.ptr(out), cols, rows, cols, _s())
+    return out
+
+
+# ------------------------------------------------------------------ pieces of the trainable stand-alone layers
+def gelu_f32(x, approximate=False, want_derivative=False):
+    """y = gelu(x) (fp32), optionally with dy/dx (activations.py:5-56: exact-erf or tanh form)."""
+    _lib.require_gpu(x)
+    if x.dtype != torch.float32:
+        raise ValueError("gelu_f32 takes fp32")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    d = torch.empty_like(x) if want_derivative else None
+    _lib.call("chb_gelu_f32", _lib.ptr(x), _lib.ptr(y), _lib.ptr(d), x.numel(), int(bool(approximate)), _s())
+    return (y, d) if want_derivative else y
+
+
+def mul_f32(a, b):
+    _lib.require_gpu(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape:
+        raise ValueError("mul_f32 takes two fp32 tensors of one shape")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    _lib.call("chb_mul_f32", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), _s())
+    return out
+
+
+def scale_by_bf16(dy, aux, out=None):
+    """bf16(dy * aux): dy fp32 or bf16, aux bf16 of the same shape (out: optional buffer whose head receives the result)."""
+    _lib.require_gpu(dy, aux)
+    if aux.dtype != torch.bfloat16 or dy.shape != aux.shape or dy.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("scale_by_bf16 takes dy (fp32 | bf16) and a bf16 aux of the same shape")
+    dy, aux = dy.contiguous(), aux.contiguous()
+    if out is None:
+        out = torch.empty(dy.shape, dtype=torch.bfloat16, device=dy.device)
+    elif out.dtype != torch.bfloat16 or not out.is_contiguous() or out.numel() < dy.numel():
+        raise ValueError("scale_by_bf16: out must be a contiguous bf16 buffer of at least dy.numel() elements")
+    _lib.call("chb_scale_by_bf16", _lib.ptr(dy), OUT_F32 if dy.dtype == torch.float32 else OUT_BF16, _lib.ptr(aux), _lib.ptr(out), dy.numel(), _s())
+    return out
+
+
+def dropout_f32(x, rate, key):
+    """x * keep / (1 - rate) with the flat-index keep mask of chb_dropout_mask (forward and backward of a Dropout layer)."""
+    _lib.require_gpu(x)
+    if x.dtype != torch.float32:
+        raise ValueError("dropout_f32 takes fp32")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.call("chb_dropout_f32", _lib.ptr(x), _lib.ptr(out), x.numel(), float(rate), ctypes.c_uint32(int(key)), _s())
+    return out
+
+
+def add_rows_f32(x, table):
+    """x [..., *table.shape] + table broadcast over the leading axes (fp32)."""
+    _lib.require_gpu(x, table)
+    if x.dtype != torch.float32 or table.dtype != torch.float32 or x.numel() % max(table.numel(), 1):
+        raise ValueError("add_rows_f32 takes fp32 x whose trailing axes are the table's")
+    x, table = x.contiguous(), table.contiguous()
+    out = torch.empty_like(x)
+    _lib.call("chb_add_rows_f32", _lib.ptr(x), _lib.ptr(table), _lib.ptr(out), x.numel(), table.numel(), _s())
+    return out
+
+
+def sum_rows_f32(x, rows, cols, row_stride=None, offset=0):
+    """out[c] = sum_r x.flat[offset + r * row_stride + c] (fp32): the batch reduction of an embedding gradient."""
+    _lib.require_gpu(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("sum_rows_f32 takes a contiguous fp32 tensor")
+    row_stride = cols if row_stride is None else row_stride
+    if offset + (rows - 1) * row_stride + cols > x.numel():
+        raise ValueError("sum_rows_f32: window exceeds the tensor")
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    _lib.call("chb_sum_rows_f32", ctypes.c_void_p(x.data_ptr() + 4 * offset), int(row_stride), int(rows), int(cols), _lib.ptr(out), _s())
     return out

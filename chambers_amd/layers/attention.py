@@ -9,7 +9,8 @@ import torch
 
 from .. import kernels as K
 from .._keras_like import Layer, register_keras_serializable
-from .core import _bf16, _next_key
+from . import autograd as AG
+from .core import _next_key
 
 
 @register_keras_serializable(package="Chambers")
@@ -37,13 +38,11 @@ class ScaledAttention(Layer):
         if k.shape != q.shape or v.shape != q.shape:
             raise ValueError("the fused attention kernel needs equal query/key/value shapes (self-attention)")
         d = h * hd
-        qkv = torch.empty((b * t, 3 * d), dtype=torch.bfloat16, device=q.device)
-        for j, x in enumerate((q, k, v)):
-            qkv[:, j * d:(j + 1) * d] = _bf16(x).permute(0, 2, 1, 3).reshape(b * t, d)
-        o = torch.empty((b * t, d), dtype=torch.bfloat16, device=q.device)
-        lse = torch.empty(b * h * t, dtype=torch.float32, device=q.device)
+        # pack [q | k | v] as the fused kernel wants them: [B*T, 3*H*hd] (pure data movement: permute + concatenate; autograd routes
+        # the packed gradient back through the same views)
+        qkv = torch.cat([x.permute(0, 2, 1, 3).reshape(b * t, d) for x in (q, k, v)], dim=1)
         rate = self.dropout if training else 0.0
-        K.attention_fwd(qkv, o, lse, b, t, h, hd, rate, (_next_key(self._site) if key is None else key) if rate else 0)
+        o = AG.AttentionFn.apply(qkv, b, t, h, hd, rate, (_next_key(self._site) if key is None else key) if rate else 0)
         return o.reshape(b, t, h, hd).permute(0, 2, 1, 3)
 
     def get_config(self):
@@ -62,7 +61,6 @@ class MultiHeadAttention(Layer):
         self.dropout_rate = dropout_rate
         self.causal = causal
         self.attention = ScaledAttention(key_dim=head_dim, causal=causal, dropout=dropout_rate)
-        self._opver = -1
 
     def build(self, input_shape):
         d = input_shape[0][-1]
@@ -77,18 +75,15 @@ class MultiHeadAttention(Layer):
         self.w_projection = self.add_weight("w_projection", (n, d, h), init)
         self.b_projection = self.add_weight("b_projection", (1, d), "zeros")
 
-    def _operands(self):
-        if self._opver != self._version:
-            d = self.w_query.shape[0]
-            nh = self.num_heads * self.head_dim
-            w = torch.cat([self.w_query.value.reshape(d, nh), self.w_key.value.reshape(d, nh), self.w_value.value.reshape(d, nh)], dim=1)
-            self._wqkv_t = w.to(torch.bfloat16).t().contiguous()                       # [3*nh, d]
-            self._bqkv = torch.cat([self.b_query.value.reshape(nh), self.b_key.value.reshape(nh), self.b_value.value.reshape(nh)]).contiguous()
-            wp = self.w_projection.value.permute(0, 2, 1).reshape(nh, d)                # [(n,h), d]
-            self._wp_t = wp.to(torch.bfloat16).t().contiguous()                        # [d, nh]
-            self._bp = self.b_projection.value.reshape(d).contiguous()
-            self._opver = self._version
-        return self._wqkv_t, self._bqkv, self._wp_t, self._bp
+    def _fused_weights(self):
+        """[w_query | w_key | w_value] as one [d, 3*n*h] kernel (+ bias) and the projection as [n*h, d]: reshapes and a concatenation
+        of the Keras-shaped variables (data movement on the tape, so each variable receives its slice of the fused gradient)."""
+        d = self.w_query.shape[0]
+        nh = self.num_heads * self.head_dim
+        w = torch.cat([self.w_query.value.reshape(d, nh), self.w_key.value.reshape(d, nh), self.w_value.value.reshape(d, nh)], dim=1)
+        bqkv = torch.cat([self.b_query.value.reshape(nh), self.b_key.value.reshape(nh), self.b_value.value.reshape(nh)])
+        wp = self.w_projection.value.permute(0, 2, 1).reshape(nh, d)                # [(n,h), d]
+        return w, bqkv, wp, self.b_projection.value.reshape(d)
 
     def call(self, inputs, mask=None, training=None, key=None, **kwargs):
         q = inputs[0]
@@ -99,17 +94,11 @@ class MultiHeadAttention(Layer):
         if mask is not None and any(m is not None for m in mask):
             raise ValueError("attention masks are not on the ViT path")
         b, t, d = q.shape
-        nh = self.num_heads * self.head_dim
-        wqkv_t, bqkv, wp_t, bp = self._operands()
-        x = _bf16(q.reshape(b * t, d)).contiguous()
-        qkv = torch.empty((b * t, 3 * nh), dtype=torch.bfloat16, device=q.device)
-        K.gemm_nt(x, wqkv_t, qkv, bias=bqkv)
-        o = torch.empty((b * t, nh), dtype=torch.bfloat16, device=q.device)
-        lse = torch.empty(b * self.num_heads * t, dtype=torch.float32, device=q.device)
+        w, bqkv, wp, bp = self._fused_weights()
+        qkv = AG.LinearFn.apply(q.reshape(b * t, d), w, bqkv, None, True)                     # bf16 [B*T, 3*n*h]
         rate = self.dropout_rate if training else 0.0
-        K.attention_fwd(qkv, o, lse, b, t, self.num_heads, self.head_dim, rate, (_next_key(self._site) if key is None else key) if rate else 0)
-        out = torch.empty((b * t, d), dtype=torch.float32, device=q.device)
-        K.gemm_nt(o, wp_t, out, bias=bp)
+        o = AG.AttentionFn.apply(qkv, b, t, self.num_heads, self.head_dim, rate, (_next_key(self._site) if key is None else key) if rate else 0)
+        out = AG.LinearFn.apply(o, wp, bp, None, False)                                        # fp32 [B*T, d]
         return out.reshape(b, t, d)
 
     def get_config(self):

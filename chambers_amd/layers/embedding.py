@@ -1,14 +1,11 @@
 """chambers.layers.embedding on MI355X: ConcatEmbedding (class token) and LearnedEmbedding1D (positional table),
 reference chambers/layers/embedding.py:156-182,218-261.  In the whole-model engine these two are fused into the
 patch-embedding GEMM epilogue; the standalone layers below are the API-surface form (pure data movement)."""
-import ctypes
-
 import torch
 
 from .._keras_like import Layer, register_keras_serializable
-from .. import _lib
 from .. import initializers
-from .. import kernels as K
+from . import autograd as AG
 
 
 @register_keras_serializable(package="Chambers")
@@ -24,7 +21,7 @@ class LearnedEmbedding1D(Layer):
 
     def call(self, inputs, **kwargs):
         if self.add_to_input:
-            return inputs + self.embedding.value.to(inputs.dtype)
+            return AG.AddTableFn.apply(inputs, self.embedding.value)        # fp32 [B, N, D]; d(embeddings) = sum over the batch
         return self.embedding.value
 
     def get_config(self):
@@ -52,21 +49,10 @@ class ConcatEmbedding(Layer):
         self.embedding = self.add_weight("embeddings", [self.n_embeddings, self.embedding_dim], self.initializer)
 
     def call(self, inputs, **kwargs):
-        batch_size = inputs.shape[0]
-        if self.axis in (1, -2) and inputs.dim() == 3 and inputs.is_cuda and inputs.dtype == self.embedding.value.dtype:
-            # tf.concat along the token axis as strided row copies (the embedding rows are read with stride 0 over the batch)
-            b, n, d = inputs.shape
-            es = inputs.element_size()
-            out = torch.empty((b, n + self.n_embeddings, d), dtype=inputs.dtype, device=inputs.device)
-            emb, x = self.embedding.value.contiguous(), inputs.contiguous()
-            e_at, x_at = (0, self.n_embeddings) if self.side == "left" else (n, 0)
-            row = (n + self.n_embeddings) * d * es
-            _lib.call("chb_copy_rows", _lib.ptr(emb), 0, ctypes.c_void_p(out.data_ptr() + e_at * d * es), row, b, self.n_embeddings * d * es, K._s())
-            _lib.call("chb_copy_rows", _lib.ptr(x), n * d * es, ctypes.c_void_p(out.data_ptr() + x_at * d * es), row, b, n * d * es, K._s())
-            return out
-        embedding = self.embedding.value.to(inputs.dtype).unsqueeze(0).expand(batch_size, self.n_embeddings, self.embedding_dim)
-        x = [embedding, inputs] if self.side == "left" else [inputs, embedding]
-        return torch.cat(x, dim=self.axis)
+        if not (self.axis in (1, -2) and inputs.dim() == 3):
+            raise ValueError("ConcatEmbedding on MI355X concatenates along the token axis of a [batch, tokens, dim] tensor (axis=1), the "
+                             "form the ViT builders use (vision_transformer.py:249-256); got axis=%r on a %d-D input" % (self.axis, inputs.dim()))
+        return AG.ConcatTokensFn.apply(inputs, self.embedding.value, self.side == "left")
 
     def compute_output_shape(self, input_shape):
         shape = list(input_shape)

@@ -5,11 +5,11 @@ The standalone layers execute the same HIP kernels as the whole-model engine, on
 stream is float32 [B, T, D]."""
 import torch
 
-from .. import kernels as K
 from .._keras_like import Layer, register_keras_serializable
 from ..activations import gelu
+from . import autograd as AG
 from .attention import MultiHeadAttention
-from .core import Dense, Dropout, LayerNormalization, _bf16, _next_key
+from .core import Dense, Dropout, LayerNormalization, _next_key
 
 
 @register_keras_serializable(package="Chambers")
@@ -50,40 +50,40 @@ class EncoderLayer(Layer):
         self.dense2.build(shape[:-1] + (self.ff_dim,)); self.dense2.built = True
         self.norm2.build(shape); self.norm2.built = True
 
+    def _attention_branch(self, h, resid, training, keys, rate):
+        """resid + dropout1(multi_head_attention(h)) (layers/transformer.py:53-58,66-69): QKV projection, fused attention, and the output
+        projection with dropout + residual in its GEMM epilogue - the engine's fusion, on the autograd tape."""
+        m = self.multi_head_attention
+        b, t, d = resid.shape
+        w, bqkv, wp, bp = m._fused_weights()
+        qkv = AG.LinearFn.apply(h.reshape(b * t, d), w, bqkv, None, True)
+        arate = m.dropout_rate if training else 0.0
+        o = AG.AttentionFn.apply(qkv, b, t, m.num_heads, m.head_dim, arate, (keys.get("attn") or _next_key(m._site)) if arate else 0)
+        return AG.LinearResidualFn.apply(o, wp, bp, resid.reshape(b * t, d), rate, (keys.get("proj") or _next_key(self._site)) if rate else 0).reshape(b, t, d)
+
+    def _mlp_branch(self, h, resid, keys, rate):
+        """resid + dropout2(dense2(dense1(h))) (layers/transformer.py:60-63,72-76): GELU in dense1's epilogue, dropout + residual in dense2's."""
+        b, t, d = resid.shape
+        u = AG.LinearFn.apply(h.reshape(b * t, d), self.dense1.kernel.value, self.dense1.bias.value, "gelu", True)      # bf16 [B*T, ff]
+        return AG.LinearResidualFn.apply(u, self.dense2.kernel.value, self.dense2.bias.value, resid.reshape(b * t, d), rate,
+                                         (keys.get("mlp") or _next_key(self._site + 1)) if rate else 0).reshape(b, t, d)
+
     def call(self, inputs, mask=None, training=None, keys=None, **kwargs):
         if mask is not None:
             raise ValueError("attention masks are not on the ViT path")
         keys = keys or {}
         rate = self.dense_dropout_rate if training else 0.0
-        x = inputs.to(torch.float32).contiguous()
-        b, t, d = x.shape
-        x2 = x.reshape(b * t, d)
+        x = inputs
+        if x.dtype != torch.float32:
+            x = x.to(torch.float32)
         if not self.pre_norm:
             # the reference's default, layers/transformer.py:59-61: x = norm1(x + attn(x)); x = norm2(x + mlp(x)).  Same kernels as the
-            # pre-norm block (the ViT's), composed the other way round; the residual of the MLP branch rides in dense2's epilogue.
-            a = self.multi_head_attention([x, x, x], training=training, key=keys.get("attn"))
-            a = self.dropout1(a, training=training, key=keys.get("proj"))
-            x1 = self.norm1(K.add_f32(x2, K.cast_f32(a).reshape(b * t, d)).reshape(b, t, d))
-            x1 = K.cast_f32(x1).reshape(b * t, d).contiguous()
-            u = self.dense1(x1.reshape(b, t, d))
-            y = torch.empty((b * t, d), dtype=torch.float32, device=x.device)
-            K.gemm_nt(_bf16(u.reshape(b * t, self.ff_dim)).contiguous(), self.dense2._cache.get(self.dense2, self.dense2.kernel), y,
-                      bias=self.dense2.bias.value, epilogue=K.EPI_RESID, resid=x1, drop_rate=rate,
-                      drop_key=(keys.get("mlp") or _next_key(self._site)) if rate else 0)
-            return K.cast_f32(self.norm2(y.reshape(b, t, d))).reshape(b, t, d)
-        h = self.norm1(x)
-        a = self.multi_head_attention([h, h, h], training=training, key=keys.get("attn"))
-        # x = x + dropout1(attn): fused as the residual epilogue's element-wise form
-        a = self.dropout1(a, training=training, key=keys.get("proj"))
-        x2 = K.add_f32(x2, K.cast_f32(a).reshape(b * t, d))
-        h2 = self.norm2(x2.reshape(b, t, d))
-        u = self.dense1(h2)
-        # dense2 with the residual + dropout fused into the GEMM epilogue
-        out = torch.empty((b * t, d), dtype=torch.float32, device=x.device)
-        K.gemm_nt(_bf16(u.reshape(b * t, self.ff_dim)).contiguous(), self.dense2._cache.get(self.dense2, self.dense2.kernel), out,
-                  bias=self.dense2.bias.value, epilogue=K.EPI_RESID, resid=x2.contiguous(), drop_rate=rate,
-                  drop_key=(keys.get("mlp") or _next_key(self._site)) if rate else 0)
-        return out.reshape(b, t, d)
+            # pre-norm block (the ViT's), composed the other way round.
+            x1 = self.norm1(self._attention_branch(x, x, training, keys, rate))            # bf16
+            y = self._mlp_branch(x1, x1, keys, rate)
+            return AG.CastF32Fn.apply(self.norm2(y))
+        x_mid = self._attention_branch(self.norm1(x), x, training, keys, rate)
+        return self._mlp_branch(self.norm2(x_mid), x_mid, keys, rate)
 
     def get_config(self):
         config = {"embed_dim": self.embed_dim, "num_heads": self.num_heads, "ff_dim": self.ff_dim,

@@ -44,6 +44,46 @@ class AdamW:
         engine.adamw_step(learning_rate=self._value(self.learning_rate, step), beta_1=self.beta_1, beta_2=self.beta_2, epsilon=self.epsilon,
                           weight_decay=self._value(self.weight_decay, step))
 
+    def apply_gradients(self, grads_and_vars, name=None, **kwargs):
+        """keras OptimizerV2.apply_gradients for models composed from the stand-alone layers: an iterable of (gradient, variable)
+        pairs, variable = chambers_amd._keras_like.Variable (gradient None: taken from `variable.value.grad`, where
+        `loss.backward()` left it).  Per variable the fused HIP update of `apply` (chb_adamw): decay first where
+        `_is_decay_allowed(variable.name)` (optimizers.py:147-155,169-181), then keras Adam.  Adam moments live in the optimizer,
+        keyed by variable, as keras slots do; `iterations` counts calls."""
+        import numpy as np
+        import torch
+        from . import kernels as K
+        step = getattr(self, "iterations", 0)
+        lr = np.float32(self._value(self.learning_rate, step))
+        wd = self._value(self.weight_decay, step)
+        t = step + 1
+        b1, b2 = np.float32(self.beta_1), np.float32(self.beta_2)
+        lr_t = float(lr * np.sqrt(np.float32(1.0) - np.power(b2, np.float32(t))) / (np.float32(1.0) - np.power(b1, np.float32(t))))
+        slots = self.__dict__.setdefault("_slots", {})
+        for grad, var in grads_and_vars:
+            g = var.value.grad if grad is None else grad
+            if g is None:
+                continue
+            p = var.value.detach()
+            n = p.numel()
+            n4 = (n + 3) // 4 * 4
+            st = slots.get(id(var))
+            if st is None:
+                st = slots[id(var)] = (torch.zeros(n4, dtype=torch.float32, device=p.device), torch.zeros(n4, dtype=torch.float32, device=p.device))
+            if n4 != n or not p.is_contiguous():          # odd sizes: update a padded copy (chb_adamw works on float4)
+                pp = torch.zeros(n4, dtype=torch.float32, device=p.device)
+                pp[:n] = p.reshape(-1)
+                gg = torch.zeros(n4, dtype=torch.float32, device=p.device)
+                gg[:n] = g.detach().reshape(-1)
+            else:
+                pp, gg = p.view(-1), g.detach().to(torch.float32).contiguous().view(-1)
+            K.adamw(pp, gg, st[0], st[1], None, lr_t, float(self.beta_1), float(self.beta_2), float(self.epsilon),
+                    float(wd) if self._is_decay_allowed(var.name) else 0.0)
+            if pp.data_ptr() != p.data_ptr():
+                with torch.no_grad():
+                    var.value.copy_(pp[:n].reshape(p.shape))
+        self.iterations = t
+
     def get_config(self):
         return {"name": self.name, "learning_rate": self.learning_rate, "beta_1": self.beta_1, "beta_2": self.beta_2, "epsilon": self.epsilon,
                 "amsgrad": self.amsgrad, "weight_decay": self.weight_decay, "decay_include": self.decay_include,

@@ -327,6 +327,24 @@ int chb_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 int chb_copy_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes, int64_t rows, int64_t row_bytes, void* stream);
 int chb_softmax_f32(const float* x, int64_t ld, float* out, int64_t ld_out, int rows, int cols, void* stream);
 
+/* Pieces of the TRAINABLE stand-alone layers (chambers_amd/layers: torch.autograd.Function wrappers over this ABI; the whole-model
+ * engine has these fused into its GEMM / LayerNorm epilogues):
+ * chb_gelu_f32: y = gelu(x), dydx (optional) = gelu'(x); approximate = 0 the exact-erf form, 1 the tanh form (activations.py:5-56).
+ * chb_mul_f32: out = a * b (backward of the stand-alone activation).
+ * chb_scale_by_bf16: out_bf16 = bf16(dy * aux_bf16), dy fp32 (CHB_OUT_F32) or bf16 (CHB_OUT_BF16) - backward of Dense(activation=gelu)
+ *   from the gelu' its forward GEMM epilogue saved (layers/transformer.py:42-44).
+ * chb_dropout_f32: out = x * keep / (1 - rate), keep = the chb_dropout_mask definition on the FLAT element index - keras Dropout as a
+ *   layer (layers/transformer.py:38,48; vision_transformer.py:261), forward and backward alike.
+ * chb_add_rows_f32: out[i] = x[i] + table[i mod period] - LearnedEmbedding1D (layers/embedding.py:156-182), period = tokens * dim.
+ * chb_sum_rows_f32: out[c] = sum_r x[r * row_stride + c] - the batch reduction in the backward of LearnedEmbedding1D / ConcatEmbedding
+ *   (layers/embedding.py:218-261). */
+int chb_gelu_f32(const float* x, float* y, float* dydx, int64_t n, int approximate, void* stream);
+int chb_mul_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int chb_scale_by_bf16(const void* dy, int dy_dtype, const void* aux_bf16, void* out_bf16, int64_t n, void* stream);
+int chb_dropout_f32(const float* x, float* out, int64_t n, float rate, uint32_t key, void* stream);
+int chb_add_rows_f32(const float* x, const float* table, float* out, int64_t n, int64_t period, void* stream);
+int chb_sum_rows_f32(const float* x, int64_t row_stride, int64_t rows, int64_t cols, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
