@@ -64,7 +64,10 @@ class EncoderLayer(Layer):
     def _mlp_branch(self, h, resid, keys, rate):
         """resid + dropout2(dense2(dense1(h))) (layers/transformer.py:60-63,72-76): GELU in dense1's epilogue, dropout + residual in dense2's."""
         b, t, d = resid.shape
-        u = AG.LinearFn.apply(h.reshape(b * t, d), self.dense1.kernel.value, self.dense1.bias.value, "gelu", True)      # bf16 [B*T, ff]
+        # u stays fp32 ON THE TAPE (dense2 rounds it to bf16 once, as the engine's stored u): its gradient then comes back in fp32 and
+        # dense1's backward rounds d(a1) = d(u) * gelu' to bf16 ONCE - the engine's gelu'-multiply epilogue; a bf16 u would force a
+        # bf16 d(u) and a second rounding
+        u = AG.LinearFn.apply(h.reshape(b * t, d), self.dense1.kernel.value, self.dense1.bias.value, "gelu", False)     # fp32 [B*T, ff]
         return AG.LinearResidualFn.apply(u, self.dense2.kernel.value, self.dense2.bias.value, resid.reshape(b * t, d), rate,
                                          (keys.get("mlp") or _next_key(self._site + 1)) if rate else 0).reshape(b, t, d)
 

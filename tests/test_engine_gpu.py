@@ -464,8 +464,8 @@ def test_training_steps_track_huggingface_vit_with_torch_adamw():
 
 def test_ragged_token_count_runs_on_padded_tiles_and_pad_rows_stay_zero():
     """M = batch x tokens that is not a multiple of 256 (config 5's situation: 128 x 577) is LAUNCHED over Mp = full 256-row tiles so
-    the block GEMMs take the full-tile kernel.  Invariants: (a) nothing observable changes - logits, loss, every gradient and the
-    weights after AdamW are bit-identical to the engine launched over the true M (pad_m=False); (b) after backward every pad row of
+    the block GEMMs take the full-tile kernel.  Invariants: (a) nothing observable changes - logits and loss are bit-identical to the
+    engine launched over the true M (pad_m=False), every gradient and the weights after AdamW equal to fp32 summation order; (b) after backward every pad row of
     every gradient-side token matrix is exactly zero (so column sums and weight-gradient GEMMs over Mp rows add nothing);
     (c) reductions over tokens used the true M (the LayerNorm / bias gradients are part of (a))."""
     from chambers_amd.engine import ViTEngine
@@ -500,9 +500,11 @@ def test_ragged_token_count_runs_on_padded_tiles_and_pad_rows_stay_zero():
         e.adamw_step(learning_rate=1e-3, weight_decay=0.05)
         out[pad] = (logits.cpu(), loss.cpu(), grads, e.export_keras_weights())
     assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    # gradients: the same products summed; weight-gradient partials of the small GEMMs meet in fp32 atomics whose order is not fixed
+    # from launch to launch, so "identical" is to the last fp32 bit of the accumulation order (~1e-7), not bitwise
     for k in out[True][2]:
-        np.testing.assert_array_equal(out[True][2][k], out[False][2][k], err_msg="gradient " + k)
-        np.testing.assert_array_equal(out[True][3][k], out[False][3][k], err_msg="weights after AdamW " + k)
+        assert rel_l2(out[True][2][k], out[False][2][k]) < 2e-6, "gradient " + k
+        assert rel_l2(out[True][3][k], out[False][3][k]) < 2e-6, "weights after AdamW " + k
     # a second step on the padded engine: junk in forward pad rows has been through a whole step and is still harmless
     e = engs[True]
     e.forward(torch.as_tensor(images, device="cuda"), training=True)
