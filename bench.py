@@ -293,6 +293,11 @@ def main():
     ap.add_argument("--elementwise", action="store_true", help="per-image augmentation decisions (the schemes' elementwise=True mode)")
     ap.add_argument("--unfused-augment", action="store_true", help="batch-shared chain as one launch per op + a separate patchify pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N ranks on one GPU")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="N = 1 only: initialise a ONE-rank process group on the chosen backend and drive the gradient exchange through it "
+                         "(every collective is issued and waited for; a one-rank all-reduce returns its input) - the RCCL code path on one GPU")
+    ap.add_argument("--grad-payload", default=os.environ.get("CHB_GRAD_PAYLOAD", "fp32"), choices=("fp32", "bf16"),
+                    help="dtype the gradient slices are all-reduced in (bf16: half the bytes, one extra rounding per contribution)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,9 +311,15 @@ def main():
     torch.cuda.set_device(local_rank)
     ensure_library(int(os.environ.get("LOCAL_RANK", "0")))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            sock.close()
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -323,7 +334,8 @@ def main():
 
     cfg_kwargs = dict(MODELS[args.model], dropout_rate=0.1, image_size=(args.image_size, args.image_size), classes=1000)
     cfg = ViTConfig(**cfg_kwargs)
-    eng = ViTEngine(cfg, args.batch, training=True, seed=rank)      # dropout masks differ per rank, like the data
+    eng = ViTEngine(cfg, args.batch, training=True, seed=rank, grad_payload=args.grad_payload,      # dropout masks differ per rank, like the data
+                    force_dp=args.force_dp and world == 1)
     eng.load_keras_weights(init_keras_weights(cfg, seed=1234))      # same init on every rank
     g = np.random.Generator(np.random.PCG64(rank))                  # synthetic data: seed = rank
     images = torch.as_tensor(g.integers(0, 256, size=(args.batch, args.image_size, args.image_size, 3), dtype=np.uint8), device="cuda")
@@ -456,7 +468,8 @@ def main():
             # the data-parallel exchange, as this run did it: collectives per step, bytes all-reduced per step per rank, the time
             # per step the compute stream stood waiting for them (HIP events around the reducer's waits on rank 0), and the
             # exposed cost = this step minus the same step re-timed with the exchange off (max over ranks, same K steps)
-            "dp": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
+            "dp": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if dist is not None else None,
+                   "payload": args.grad_payload, "forced_single_rank_group": bool(args.force_dp and world == 1),
                    "world_size": dist.get_world_size() if dist is not None else 1,
                    "allreduce_bytes_per_step": red.bytes_reduced / args.steps, "collectives_per_step": red.n_collectives / args.steps,
                    "reducer_wait_ms_per_step": red.exposed_ms() / args.steps,

@@ -313,6 +313,10 @@ int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, 
  * process; nothing on the launch path calls getenv.  Results are identical under every setting (the parity tests
  * cross-check them); only speed changes. */
 int chb_set_option(const char* name, int value);
+/* Zero the tile-queue counters of the persistent NT GEMMs (GEMM_TILE_QUEUE = 1; default 0 = static tile shares, no counters used):
+ * the only device state the library keeps between launches.  Launches clean up behind themselves; this is for the start of a run
+ * and for recovery after a faulted launch.  Ordered on `stream`. */
+int chb_gemm_tile_queue_reset(void* stream);
 /* x[0..n) = 0 (n % 4 == 0, 16-byte aligned): gradient buffer reset when backward runs twice without an optimizer step. */
 int chb_zero_f32(float* x, int64_t n, void* stream);
 

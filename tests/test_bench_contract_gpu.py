@@ -49,3 +49,28 @@ def test_two_rank_launch_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2 * 32 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert d["cpu_baseline"] is None
+
+
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_forced_single_rank_rccl_group(payload):
+    """`--force-dp` initialises a ONE-rank `nccl` (= RCCL) process group on the one GPU there is and drives the
+    engine's GradBucketReducer through it - init, 13 asynchronous collectives per step over the whole gradient, stream ordering and
+    finish() on the real backend.  A one-rank all-reduce returns its input, so with the fp32 payload the loss equals the plain
+    run's; with the bf16 payload every gradient is rounded to bf16 once on the way (close, not equal)."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-augment"]
+    plain = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    r = subprocess.run(base + ["--force-dp", "--grad-payload", payload], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d, p = _json_line(r.stdout), _json_line(plain.stdout)
+    dp = d["dp"]
+    assert dp["backend"] == "nccl (RCCL)" and dp["world_size"] == 1 and dp["forced_single_rank_group"] is True and dp["payload"] == payload
+    assert dp["collectives_per_step"] == 13
+    assert dp["allreduce_bytes_per_step"] == dp["gradient_bytes"] // (1 if payload == "fp32" else 2)
+    assert dp["reducer_wait_ms_per_step"] >= 0 and dp["ms_per_step_without_exchange"] > 0
+    assert p["dp"]["backend"] is None and p["dp"]["collectives_per_step"] == 0
+    if payload == "fp32":
+        assert d["final_loss"] == p["final_loss"]
+    else:
+        assert abs(d["final_loss"] - p["final_loss"]) < 2e-2 * abs(p["final_loss"])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1"
