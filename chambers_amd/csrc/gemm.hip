@@ -2305,7 +2305,6 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
     return CHB_OK;
 }
 
-#ifdef CHB_PHASE_STAMPS
 // The tile queue's per-launch-slot, per-XCD counters (g_tile_ctr) are the one piece of device state this library keeps between
 // launches.  A launch leaves its slot at zero (the holder of an XCD's last ticket clears it), so nothing needs doing in normal
 // operation; a launch that FAULTED or was aborted mid-way can leave a slot dirty, and the next launch on that slot would then
@@ -2318,6 +2317,7 @@ int chb_gemm_tile_queue_reset(void* stream) {
     return CHB_OK;
 }
 
+#ifdef CHB_PHASE_STAMPS
 int chb_debug_phase_stamps(unsigned int* host_out, int n_groups) {   // diagnostic build only
     if (n_groups > 1024) n_groups = 1024;
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_stamps), sizeof(unsigned int) * 20 * n_groups) == hipSuccess ? 0 : -1;
