@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
         }
         const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
         float4* dxr = reinterpret_cast<float4*>(dx + (int64_t)row * dx_stride);
+        // dz is a compact [rows, D] matrix over the SAME element grid as dx: with strided rows (class rows of the token matrix,
+        // dx_stride = N * D) LayerNorm row `row` is token-matrix row row * N
+        const int64_t zrow = (int64_t)row * (dx_stride / D);
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = lane + 64 * j;
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
                     // operand; its column sums are the bias gradient of that GEMM's layer
                     float4 z = o;
                     if (drop_thr) {
-                        const uint64_t e = (uint64_t)row * (uint64_t)D + (uint64_t)(c * 4);
+                        const uint64_t e = (uint64_t)zrow * (uint64_t)D + (uint64_t)(c * 4);
                         bool k0, k1, k2, k3;
                         chb_keep2((uint32_t)(e >> 1), drop_key, drop_thr, k0, k1);
                         chb_keep2((uint32_t)(e >> 1) + 1u, drop_key, drop_thr, k2, k3);
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
                     uint2 zb;
                     zb.x = pack_bf16x2(z.x, z.y);
                     zb.y = pack_bf16x2(z.z, z.w);
-                    reinterpret_cast<uint2*>(dz + (int64_t)row * D)[c] = zb;
+                    reinterpret_cast<uint2*>(dz + zrow * D)[c] = zb;
                     // sum what the GEMM will read (the bf16-rounded values), as the separate colsum pass did
                     dzs[j].x += bf16_to_f32((bf16_t)(zb.x & 0xffff)); dzs[j].y += bf16_to_f32((bf16_t)(zb.x >> 16));
                     dzs[j].z += bf16_to_f32((bf16_t)(zb.y & 0xffff)); dzs[j].w += bf16_to_f32((bf16_t)(zb.y >> 16));
@@ -155,6 +158,11 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
             float4* base = reinterpret_cast<float4*>(dx + row * dx_stride + D) + (part << 12);
             const int64_t cnt = min((int64_t)4096, gap4 - (part << 12));
             for (int64_t k = threadIdx.x; k < cnt; k += 256) base[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dz) {     // the same gap of the bf16 dz matrix: dropout-backward of a zero gradient (half the bytes: 8 elements per float4)
+                float4* zb = reinterpret_cast<float4*>(dz + row * dx_stride + D) + (part << 11);
+                const int64_t zc = min((int64_t)2048, (gap4 >> 1) - (part << 11));
+                for (int64_t k = threadIdx.x; k < zc; k += 256) zb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
     // block-level reduce of dgamma/dbeta partials over the 4 waves, then one atomic per column
@@ -213,6 +221,9 @@ int chb_layernorm_bwd(const void* dy, const float* x, int64_t x_stride, const fl
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || M < 0 || D <= 0) return CHB_EINVAL;
     if (drop_rate < 0.f || drop_rate >= 1.f) return CHB_EINVAL;
     if (zero_gaps && (accumulate || dx_stride < D)) return CHB_EINVAL;
+    // the fused dropout-backward tail writes a compact dz over dx's element grid: strided rows need whole-row strides, and the rows
+    // between them are only defined (as zeros) when this launch also fills the gaps
+    if (dz_bf16 && dx_stride != D && (!zero_gaps || dx_stride % D != 0 || ((dx_stride - D) & 7) || (D & 7))) return CHB_EINVAL;
     bf16_t* dz = (bf16_t*)dz_bf16;
     const float dscale = 1.0f / (1.0f - drop_rate);
     const uint32_t dthr = drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u;

@@ -820,23 +820,6 @@ class ViTEngine:
             K.gemm_tn(self.hf, self.dfz, self.g("feature/kernel"), m=self.Bp, ws=self.tn_ws)
             K.colsum(self.dfz, self.g("feature/bias"), m=self.B)
             K.gemm_nt(self.dfz, self.wb("feature/kernel"), self.dhf, m=self.B)
-        # pooling + final norm
-        if cfg.pooling == "cls":
-            # the class rows get their gradient, every other row of dx its zero, in one launch (zero_gaps)
-            K.layernorm_bwd(self.dhf, self.x_final, n * d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, n * d, False,
-                            self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d, zero_gaps=True)
-            if cfg.distilled:   # the distillation token's rows (sequence row 1) of the same LayerNorm
-                K.layernorm_bwd(self.dhfd, self.x_final.view(-1)[d:], n * d, self.meand, self.rstdd, self.p("encoder/norm/gamma"),
-                                self.dx.view(-1)[d:], n * d, False, self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
-        else:
-            if cfg.pooling != "none":
-                K.pool_tokens_bwd(self.dhf, self.pool_arg, self.dh, self.B, n, d, cfg.pooling)
-            if cfg.distilled:   # add the distillation head's gradient to row 1 of the normalised sequence
-                dhv = self.dh[:M].view(self.B, n, d)
-                dhv[:, 1, :] += self.dhfd[:self.B]
-            K.layernorm_bwd(self.dh, self.x_final, d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, d, False,
-                            self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), M, d)
-        self.reducer.bucket_ready(0)
         side = self.side if self.overlap_wgrad else None
 
         def nxt(name):          # next buffer of an operand the side stream reads (a ring slot, or the one buffer)
@@ -862,9 +845,30 @@ class ViTEngine:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
 
-        # dz of the last block's MLP branch (afterwards every LayerNorm backward emits the next dz + its bias gradient)
-        K.dropout_bwd(self.dx, nxt("dz"), M, d, rate, key(rng.site_mlp(L - 1)))
-        K.colsum(self.dz, self.g("encoder/layer_%d/dense2/bias" % (L - 1)), m=M)
+        # pooling + final norm.  The final LayerNorm backward also emits dz of the last block's MLP branch (dropout-backward of the
+        # residual gradient, bf16) and its column sums (dense2's bias gradient) - no separate pass over dx.
+        last = "encoder/layer_%d/dense2/bias" % (L - 1)
+        fuse_tail = not cfg.distilled
+        tail = dict(dz=nxt("dz"), dz_colsum=self.g(last), drop_rate=rate, drop_key=key(rng.site_mlp(L - 1))) if fuse_tail else {}
+        if cfg.pooling == "cls":
+            # the class rows get their gradient, every other row of dx its zero, in one launch (zero_gaps)
+            K.layernorm_bwd(self.dhf, self.x_final, n * d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, n * d, False,
+                            self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d, zero_gaps=True, **tail)
+            if cfg.distilled:   # the distillation token's rows (sequence row 1) of the same LayerNorm
+                K.layernorm_bwd(self.dhfd, self.x_final.view(-1)[d:], n * d, self.meand, self.rstdd, self.p("encoder/norm/gamma"),
+                                self.dx.view(-1)[d:], n * d, False, self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), self.B, d)
+        else:
+            if cfg.pooling != "none":
+                K.pool_tokens_bwd(self.dhf, self.pool_arg, self.dh, self.B, n, d, cfg.pooling)
+            if cfg.distilled:   # add the distillation head's gradient to row 1 of the normalised sequence
+                dhv = self.dh[:M].view(self.B, n, d)
+                dhv[:, 1, :] += self.dhfd[:self.B]
+            K.layernorm_bwd(self.dh, self.x_final, d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, d, False,
+                            self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), M, d, **tail)
+        self.reducer.bucket_ready(0)
+        if not fuse_tail:     # distilled variant: two LayerNorm launches write dx (class rows, distillation rows); dz follows them
+            K.dropout_bwd(self.dx, nxt("dz"), M, d, rate, key(rng.site_mlp(L - 1)))
+            K.colsum(self.dz, self.g(last), m=M)
         for l in reversed(range(L)):
             a = self.acts[l]
             pre = "encoder/layer_%d/" % l

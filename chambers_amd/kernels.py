@@ -408,8 +408,8 @@ def layernorm_fwd(x, x_stride, gamma, beta, y, mean, rstd, m, d, eps):
 def layernorm_bwd(dy, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, m, d, dz=None, dz_colsum=None,
                   drop_rate=0.0, drop_key=0, zero_gaps=False):
     _lib.require_gpu(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dz, dz_colsum)
-    if dz is not None and int(dx_stride) != int(d):
-        raise ValueError("the fused dropout-backward tail needs compact rows")
+    if dz is not None and int(dx_stride) != int(d) and not (zero_gaps and int(dx_stride) % int(d) == 0):
+        raise ValueError("the fused dropout-backward tail needs compact rows, or strided rows whose gaps this launch zero-fills")
     _lib.call("chb_layernorm_bwd", _lib.ptr(dy), _lib.ptr(x), int(x_stride), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dx),
               int(dx_stride), int(bool(accumulate)), _lib.ptr(dgamma), _lib.ptr(dbeta), int(m), int(d), _lib.ptr(dz), _lib.ptr(dz_colsum),
               float(drop_rate), ctypes.c_uint32(int(drop_key)), int(bool(zero_gaps)), _s())

@@ -55,8 +55,8 @@ def test_two_rank_launch_over_gloo():
 def test_forced_single_rank_rccl_group(payload):
     """`--force-dp` initialises a ONE-rank `nccl` (= RCCL) process group on the one GPU there is and drives the
     engine's GradBucketReducer through it - init, 13 asynchronous collectives per step over the whole gradient, stream ordering and
-    finish() on the real backend.  A one-rank all-reduce returns its input, so with the fp32 payload the loss equals the plain
-    run's; with the bf16 payload every gradient is rounded to bf16 once on the way (close, not equal)."""
+    finish() on the real backend.  A one-rank all-reduce returns its input (the bf16 payload rounds every gradient to bf16 once on the
+    way), so the run trains like the plain one."""
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-augment"]
     plain = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert plain.returncode == 0, plain.stderr[-2000:]
@@ -69,8 +69,7 @@ def test_forced_single_rank_rccl_group(payload):
     assert dp["allreduce_bytes_per_step"] == dp["gradient_bytes"] // (1 if payload == "fp32" else 2)
     assert dp["reducer_wait_ms_per_step"] >= 0 and dp["ms_per_step_without_exchange"] > 0
     assert p["dp"]["backend"] is None and p["dp"]["collectives_per_step"] == 0
-    if payload == "fp32":
-        assert d["final_loss"] == p["final_loss"]
-    else:
-        assert abs(d["final_loss"] - p["final_loss"]) < 2e-2 * abs(p["final_loss"])
+    # two runs of the same step already differ in the last bits (fp32 atomics in the small weight-gradient reductions, amplified by
+    # Adam's first steps): "the same training" is agreement of the loss after four steps to 1e-3, for either payload
+    assert abs(d["final_loss"] - p["final_loss"]) < 1e-3 * abs(p["final_loss"])
     assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1"

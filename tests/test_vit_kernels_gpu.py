@@ -501,6 +501,36 @@ def test_layernorm_bwd_fused_dropout_tail():
     assert rel_l2(zsum.cpu(), cs.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("rate", [0.0, 0.1])
+def test_layernorm_bwd_class_rows_with_the_fused_dropout_tail(rate):
+    """The final LayerNorm's backward over the class rows (strided, gaps zero-filled) also emits dz = bf16(dropout-backward of dx)
+    for EVERY token row (zeros between the class rows) and its column sums: equal to the separate dropout-backward + colsum passes."""
+    from chambers_amd import kernels as K
+    bsz, n, d, key = 5, 17, 192, 4242
+    x = torch.randn(bsz * n, d, generator=g(91)).cuda()
+    gamma = torch.randn(d, generator=g(92)).cuda()
+    dy = bf(torch.randn(bsz, d, generator=g(93))).cuda()
+    xr = x.view(bsz, n, d)[:, 0, :]
+    mean = xr.mean(-1).contiguous()
+    rstd = (1.0 / torch.sqrt(xr.var(-1, unbiased=False) + 1e-6)).contiguous()
+    dg1, db1, dg2, db2 = (torch.zeros(d, device="cuda") for _ in range(4))
+    dx_a = torch.full((bsz * n, d), 3.0, device="cuda")
+    K.layernorm_bwd(dy, x, n * d, mean, rstd, gamma, dx_a, n * d, False, dg1, db1, bsz, d, zero_gaps=True)
+    ref = torch.empty(bsz * n, d, dtype=torch.bfloat16, device="cuda")
+    K.dropout_bwd(dx_a, ref, bsz * n, d, rate, key)
+    cs = torch.zeros(d, device="cuda")
+    K.colsum(ref, cs)
+    dx_b = torch.full((bsz * n, d), 3.0, device="cuda")
+    dz = torch.full((bsz * n + 2, d), 9.0, dtype=torch.bfloat16, device="cuda")
+    zsum = torch.zeros(d, device="cuda")
+    K.layernorm_bwd(dy, x, n * d, mean, rstd, gamma, dx_b, n * d, False, dg2, db2, bsz, d, dz=dz, dz_colsum=zsum, drop_rate=rate, drop_key=key,
+                    zero_gaps=True)
+    assert torch.equal(dx_a, dx_b) and torch.equal(dz[:bsz * n], ref) and bool((dz[bsz * n:] == 9.0).all())
+    assert rel_l2(zsum.cpu(), cs.cpu()) < 1e-5
+    with pytest.raises(ValueError):            # strided rows without the gap fill leave the rows between undefined: refused
+        K.layernorm_bwd(dy, x, n * d, mean, rstd, gamma, dx_b, n * d, False, dg2, db2, bsz, d, dz=dz, dz_colsum=zsum)
+
+
 def test_layernorm_strided_rows():
     from chambers_amd import kernels as K
     bsz, n, d = 4, 5, 192
