@@ -10,8 +10,9 @@ next to the bf16 STORAGE floor: the relative L2 distance between the fp32-oracle
 bf16 (only meaningful for tensors the build stores in bf16; ~1.6e-3 for random data: 8 significant bits).  A tensor the
 build stores in bf16 cannot be closer to the fp32 oracle than that floor, whatever the kernel does.
 
-tests/test_fp_bar_gpu.py asserts the reduced-depth rows against BOUNDS below (measured x 1.5); DESIGN.md section 2 carries
-the full-depth table this script prints with --full.
+tests/test_fp_bar_gpu.py asserts the fp32 column of the reduced-depth rows against the rounding-point BUDGET of tests/fp_budget.py
+(floor x sqrt(k + kappa^2) x 1.5) and the emulated column against tight measured bounds; DESIGN.md section 2 carries the full-depth
+table this script prints with --full.
 """
 import json
 import os
@@ -111,6 +112,8 @@ def measure(name, depth=None, dropout=0.1, seed=3, threads=None):
     keys = {s: rng_ref.site_key(seed, 0, s) for s in range(1 + 3 * L)} if train else None
     rows = {}
     refs = {}
+    kap = {}
+    rng_ref_site_attn = vit_ref.site_attn
     for mode in ("fp32", "emu"):
         p = {k: torch.tensor(v, dtype=torch.float32, requires_grad=train) for k, v in kw.items()}
         taps = {}
@@ -128,6 +131,14 @@ def measure(name, depth=None, dropout=0.1, seed=3, threads=None):
                 pre0 = "encoder/layer_0/multi_head_attention/"
                 ref["dq (block 0)"], ref["dk (block 0)"], ref["dv (block 0)"] = (taps[pre0 + c].grad for c in "qkv")
                 ref["dO (block 0)"] = taps[pre0 + "o"].grad
+                if mode == "fp32":      # cancellation ratios of the attention backward's rounded-operand products (tests/fp_budget.py)
+                    from fp_budget import attention_kappas
+                    keep, inv_keep = None, 1.0
+                    if kwargs["dropout_rate"]:
+                        keep = torch.from_numpy(rng_ref.attn_keep_mask((bsz, h, n, n), keys[rng_ref_site_attn(0)], kwargs["dropout_rate"]))
+                        inv_keep = float(np.float32(1.0) / (np.float32(1.0) - np.float32(kwargs["dropout_rate"])))
+                    kap = attention_kappas(*(taps[pre0 + c].detach() for c in "qkv"), taps[pre0 + "o"].detach(), taps[pre0 + "o"].grad,
+                                           keep, inv_keep)
                 for fam, suffixes in FAMILIES:
                     ks = [k for k in kw if k.endswith(suffixes) and not k.endswith("b_key")]
                     if ks:
@@ -137,7 +148,9 @@ def measure(name, depth=None, dropout=0.1, seed=3, threads=None):
     stored_bf16 = {"o (last block)", "o (block 0)", "dq (block 0)", "dk (block 0)", "dv (block 0)", "dO (block 0)"}
     for row in refs["fp32"]:
         rows[row] = {"fp32": rel_l2(got[row], refs["fp32"][row]), "emu": rel_l2(got[row], refs["emu"][row]),
-                     "floor": bf16_floor(refs["fp32"][row]) if row in stored_bf16 else None}
+                     "floor": bf16_floor(refs["fp32"][row]) if row in stored_bf16 else None,
+                     "kappa": kap.get(row.split(" ")[0]) if train else None}
+    rows["_depth"] = L
     del eng
     torch.cuda.empty_cache()
     return rows
@@ -157,9 +170,12 @@ def main():
         key = "%s, depth %d" % (name, kw["n_encoder_layers"] if depth is None else depth)
         out[key] = rows
         print("== " + key, flush=True)
-        print("   %-42s %12s %12s %12s" % ("tensor", "vs fp32", "vs bf16-emu", "bf16 floor"))
+        from fp_budget import budget_for_row
+        L = rows.pop("_depth")
+        print("   %-42s %12s %12s %12s %8s %12s" % ("tensor", "vs fp32", "vs bf16-emu", "bf16 floor", "kappa", "budget(fp32)"))
         for row, v in rows.items():
-            print("   %-42s %12.3e %12.3e %12s" % (row, v["fp32"], v["emu"], "%.3e" % v["floor"] if v["floor"] is not None else "-"), flush=True)
+            print("   %-42s %12.3e %12.3e %12s %8s %12.3e" % (row, v["fp32"], v["emu"], "%.3e" % v["floor"] if v["floor"] is not None else "-",
+                                                            "%.1f" % v["kappa"] if v.get("kappa") else "-", budget_for_row(row, L, v.get("kappa"))), flush=True)
     if "--json" in sys.argv:
         with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
             json.dump(out, f, indent=1)

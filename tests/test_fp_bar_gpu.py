@@ -1,9 +1,9 @@
 """The stated floating-point bar (SURVEY 8c / north star "within 1e-3 rel for bf16 attention / FFN"), asserted per tensor.
 
 Every tensor family of one forward + loss + backward of the four BASELINE geometries (width, heads, tokens as configured; depth
-cut to 2 blocks so the CPU oracle finishes in seconds) against the plain fp32 oracle and against the oracle that emulates the
-build's bf16 rounding points, with bounds = the values measured on MI355X x 1.5 (tests/fp_bar.py prints the table; the full-depth
-table is in DESIGN.md section 2).  What the numbers mean: a tensor the build stores in bf16 sits at least one storage rounding
+cut to 2 blocks so the CPU oracle finishes in seconds) against the plain fp32 oracle - bounded by the rounding-point BUDGET of
+tests/fp_budget.py, not by "measured x 1.5" - and against the oracle that emulates the build's bf16 rounding points (tight measured
+bounds) (tests/fp_bar.py prints the table; the full-depth table is in DESIGN.md section 2).  What the numbers mean: a tensor the build stores in bf16 sits at least one storage rounding
 (rel-L2 1.65e-3 on such data) from the fp32 oracle; k independent roundings along a path add up like a random walk,
 ~1.65e-3 * sqrt(k) - logits after 2 blocks (k ~ 12) 5.9e-3, gradients ~7e-3.  The kernels themselves add nothing to the storage
 format: tests/test_vit_kernels_gpu.py holds every kernel with an fp32 output to <= 2e-6 of the fp64 result on the same bf16
@@ -13,32 +13,37 @@ import pytest
 
 from conftest import fp_check
 from fp_bar import GEOMETRIES, measure
+from fp_budget import FLOOR, budget_for_row
 
 pytestmark = pytest.mark.gpu
 
-# row -> (bound vs fp32 oracle, bound vs bf16-emulating oracle): max over the four geometries of the depth-2 measurement x 1.5
-BOUNDS = {
-    "logits": (9.3e-3, 6.6e-3),
-    "o (last block)": (5.3e-3, 1.8e-3),
-    "o (block 0)": (3.7e-3, 8.6e-4),
-    "loss per sample": (1.9e-3, 1.3e-3),
-    "dq (block 0)": (3.0e-2, 1.33e-2),
-    "dk (block 0)": (1.37e-2, 1.07e-2),
-    "dv (block 0)": (1.12e-2, 1.02e-2),
-    "dO (block 0)": (1.06e-2, 9.3e-3),
+# vs the bf16-EMULATING oracle (same rounding points: what is left are rounding flips and accumulation order) - the kernel-defect
+# detector, tight: max over the four geometries of the depth-2 measurement x 1.5.  The column against the plain fp32 oracle is
+# bounded by the rounding-point budget of tests/fp_budget.py instead (floor x sqrt(k + kappa^2) x 1.5, k counted, kappa computed).
+EMU_BOUNDS = {
+    "logits": 6.6e-3,
+    "o (last block)": 1.8e-3,
+    "o (block 0)": 8.6e-4,
+    "loss per sample": 1.3e-3,
+    "dq (block 0)": 1.33e-2,
+    "dk (block 0)": 1.07e-2,
+    "dv (block 0)": 1.02e-2,
+    "dO (block 0)": 9.3e-3,
 }
-GRAD_BOUND = (1.21e-2, 1.15e-2)      # every weight-gradient family ("d ..." rows)
-FLOOR = (1.5e-3, 1.8e-3)             # one bf16 storage rounding of such tensors (rel-L2)
+EMU_GRAD_BOUND = 1.15e-2             # every weight-gradient family ("d ..." rows)
+FLOOR_RANGE = (1.5e-3, 1.8e-3)       # one bf16 storage rounding of such tensors (rel-L2); the model's FLOOR sits inside
 
 
 @pytest.mark.parametrize("geometry", list(GEOMETRIES))
 def test_fp_bar(geometry):
     rows = measure(geometry, depth=2)
-    assert "logits" in rows and "o (last block)" in rows
+    depth = rows.pop("_depth")
+    assert depth == 2 and "logits" in rows and "o (last block)" in rows and FLOOR_RANGE[0] < FLOOR < FLOOR_RANGE[1]
     for row, v in rows.items():
-        b32, bemu = BOUNDS.get(row, GRAD_BOUND)
-        fp_check("%s | %s | vs fp32" % (geometry, row), v["fp32"], b32)
-        fp_check("%s | %s | vs bf16-emu" % (geometry, row), v["emu"], bemu)
+        b32 = budget_for_row(row, depth, v.get("kappa"))
+        fp_check("%s | %s | vs fp32 (budget: k, kappa = %s)" % (geometry, row, "%.1f" % v["kappa"] if v.get("kappa") else "-"), v["fp32"], b32)
+        fp_check("%s | %s | vs bf16-emu" % (geometry, row), v["emu"], EMU_BOUNDS.get(row, EMU_GRAD_BOUND))
+        assert v["emu"] <= v["fp32"] * 1.05 or v["emu"] < 1e-3       # sharing the rounding points can only bring the oracle closer
         if v["floor"] is not None:
-            assert FLOOR[0] < v["floor"] < FLOOR[1], (row, v["floor"])
+            assert FLOOR_RANGE[0] < v["floor"] < FLOOR_RANGE[1], (row, v["floor"])
             assert v["fp32"] > 0.5 * v["floor"]          # a bf16-stored tensor cannot be (much) closer to fp32 than one rounding
