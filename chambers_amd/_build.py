@@ -21,6 +21,7 @@ SOURCES = {
     "gemm.hip": [],
     "layernorm.hip": [],
     "attention.hip": [],
+    "attention_general.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "metric.hip": [],
 }

@@ -13,36 +13,52 @@ from . import autograd as AG
 from .core import _next_key
 
 
+def _split_mask(mask, b, tq, tk, device):
+    """`mask` = [query_mask, value_mask] (either may be None), boolean [batch, length] each (layers/attention.py:129-145: the same
+    mask for every head) -> uint8 device tensors or None."""
+    if mask is None:
+        return None, None
+    if not isinstance(mask, (list, tuple)) or len(mask) != 2:
+        raise ValueError("mask must be a list [query_mask, value_mask]")
+    return K._mask_u8(mask[0], b, tq, device), K._mask_u8(mask[1], b, tk, device)
+
+
 @register_keras_serializable(package="Chambers")
 class ScaledAttention(Layer):
-    """keras Attention with scores / sqrt(key_dim) (:7-23).  Inputs [query, value, key] are
-    [B, heads, T, head_dim] tensors; T and head_dim must match what the fused kernel supports."""
+    """keras Attention with scores / sqrt(key_dim) (:7-23).  Inputs [query, value, key] are [B, heads, T, head_dim] tensors.
+    Unmasked self-shaped attention with head_dim 64 runs the fused MFMA kernel; `mask=[query_mask, value_mask]`, `causal=True`,
+    key / value sequences of another length and other head widths run the general kernel (keras Attention's full semantics)."""
 
     _site = 9100
 
     def __init__(self, key_dim=None, causal=False, dropout=0.0, name=None, **kwargs):
         super().__init__(name=name, **kwargs)
-        if causal:
-            raise ValueError("causal attention is not on the ViT path (layers/transformer.py:31-37 builds it with causal=False)")
         self.key_dim = key_dim
         self.causal = causal
         self.dropout = dropout
         self._scale = math.sqrt(key_dim) if key_dim is not None else None
 
     def call(self, inputs, mask=None, training=None, key=None, **kwargs):
-        if mask is not None and any(m is not None for m in mask):
-            raise ValueError("attention masks are not on the ViT path")
         q, v = inputs[0], inputs[1]
         k = inputs[2] if len(inputs) > 2 else v
         b, h, t, hd = q.shape
-        if k.shape != q.shape or v.shape != q.shape:
-            raise ValueError("the fused attention kernel needs equal query/key/value shapes (self-attention)")
+        tk = k.shape[2]
+        if self.key_dim is not None and int(self.key_dim) != int(hd):
+            raise ValueError("key_dim %r does not match the head dimension %d of the inputs" % (self.key_dim, hd))
         d = h * hd
+        rate = self.dropout if training else 0.0
+        dkey = (_next_key(self._site) if key is None else key) if rate else 0
+        qmask, vmask = _split_mask(mask, b, t, tk, q.device)
+        general = qmask is not None or vmask is not None or self.causal or k.shape != q.shape or v.shape != q.shape or hd != 64
+        if general:
+            # masks / causal / cross-attention / other head widths: keras Attention's full semantics through the general kernel
+            flat = lambda x: x.permute(0, 2, 1, 3).reshape(x.shape[0] * x.shape[2], d)     # noqa: E731
+            o = AG.AttentionGeneralFn.apply(flat(q), flat(k), flat(v), b, t, tk, h, hd, vmask, qmask, self.causal, rate, dkey)
+            return o.reshape(b, t, h, hd).permute(0, 2, 1, 3)
         # pack [q | k | v] as the fused kernel wants them: [B*T, 3*H*hd] (pure data movement: permute + concatenate; autograd routes
         # the packed gradient back through the same views)
         qkv = torch.cat([x.permute(0, 2, 1, 3).reshape(b * t, d) for x in (q, k, v)], dim=1)
-        rate = self.dropout if training else 0.0
-        o = AG.AttentionFn.apply(qkv, b, t, h, hd, rate, (_next_key(self._site) if key is None else key) if rate else 0)
+        o = AG.AttentionFn.apply(qkv, b, t, h, hd, rate, dkey)
         return o.reshape(b, t, h, hd).permute(0, 2, 1, 3)
 
     def get_config(self):
@@ -89,17 +105,34 @@ class MultiHeadAttention(Layer):
         q = inputs[0]
         v = inputs[1]
         k = inputs[2] if len(inputs) > 2 else v
-        if not (q is v and q is k):
-            raise ValueError("the MI355X path implements self-attention (q is v is k), as EncoderLayer calls it (layers/transformer.py:66-68)")
-        if mask is not None and any(m is not None for m in mask):
-            raise ValueError("attention masks are not on the ViT path")
         b, t, d = q.shape
-        w, bqkv, wp, bp = self._fused_weights()
-        qkv = AG.LinearFn.apply(q.reshape(b * t, d), w, bqkv, None, True)                     # bf16 [B*T, 3*n*h]
+        tk = k.shape[1]
+        if v.shape[1] != tk:
+            raise ValueError("key and value sequences must have the same length, got %d and %d" % (tk, v.shape[1]))
         rate = self.dropout_rate if training else 0.0
-        o = AG.AttentionFn.apply(qkv, b, t, self.num_heads, self.head_dim, rate, (_next_key(self._site) if key is None else key) if rate else 0)
+        dkey = (_next_key(self._site) if key is None else key) if rate else 0
+        qmask, vmask = _split_mask(mask, b, t, tk, q.device)
+        w, bqkv, wp, bp = self._fused_weights()
+        nh = self.num_heads * self.head_dim
+        self_attention = (q is v and q is k)
+        if self_attention and qmask is None and vmask is None and not self.causal and self.head_dim == 64:
+            qkv = AG.LinearFn.apply(q.reshape(b * t, d), w, bqkv, None, True)                 # bf16 [B*T, 3*n*h]: one fused projection
+            o = AG.AttentionFn.apply(qkv, b, t, self.num_heads, self.head_dim, rate, dkey)
+        else:
+            # layers/attention.py:108-122 in full: separate projections of the three inputs (cross-attention), masks broadcast over the
+            # heads (separate_heads_mask), causal mask - through the general attention kernel
+            query = AG.LinearFn.apply(q.reshape(b * t, d), w[:, :nh], bqkv[:nh], None, True)
+            keyp = AG.LinearFn.apply(k.reshape(b * tk, k.shape[-1]), w[:, nh:2 * nh], bqkv[nh:2 * nh], None, True)
+            value = AG.LinearFn.apply(v.reshape(b * tk, v.shape[-1]), w[:, 2 * nh:], bqkv[2 * nh:], None, True)
+            o = AG.AttentionGeneralFn.apply(query, keyp, value, b, t, tk, self.num_heads, self.head_dim, vmask, qmask, self.causal, rate, dkey)
         out = AG.LinearFn.apply(o, wp, bp, None, False)                                        # fp32 [B*T, d]
         return out.reshape(b, t, d)
+
+    def compute_mask(self, inputs, mask=None):
+        """layers/attention.py:147-153: the query mask passes through."""
+        if mask:
+            return mask[0]
+        return None
 
     def get_config(self):
         config = {"head_dim": self.head_dim, "num_heads": self.num_heads, "dense_kernel_initializer": self.dense_kernel_initializer,

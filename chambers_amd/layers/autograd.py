@@ -231,6 +231,30 @@ class AttentionFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None
 
 
+class AttentionGeneralFn(torch.autograd.Function):
+    """keras Attention semantics beyond the ViT's use (layers/attention.py:99-153): value / query masks, causal mask, cross-attention
+    (Tq != Tk), through chb_attention_general_fwd / _bwd.  q [B*Tq, H*hd], k / v [B*Tk, H*hd]; masks uint8 [B, T] or None."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, b, tq, tk, h, hd, vmask, qmask, causal, rate, key):
+        qq, kk, vv = (K.cast_bf16(t.detach()).contiguous() for t in (q, k, v))
+        o, lse = K.attention_general_fwd(qq, kk, vv, b, tq, tk, h, hd, vmask, qmask, causal, rate, key if rate else 0)
+        ctx.dims = (b, tq, tk, h, hd, bool(causal), float(rate), int(key) if rate else 0)
+        ctx.dtypes = (q.dtype, k.dtype, v.dtype)
+        ctx.masks = (vmask, qmask)
+        ctx.save_for_backward(qq, kk, vv, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qq, kk, vv, o, lse = ctx.saved_tensors
+        b, tq, tk, h, hd, causal, rate, key = ctx.dims
+        dq, dk, dv = K.attention_general_bwd(qq, kk, vv, o, K.cast_bf16(do).contiguous(), lse, b, tq, tk, h, hd, ctx.masks[0], ctx.masks[1],
+                                             causal, rate, key)
+        out = [K.cast_bf16(g) if dt == torch.bfloat16 else g for g, dt in zip((dq, dk, dv), ctx.dtypes)]
+        return (out[0], out[1], out[2]) + (None,) * 10
+
+
 class DropoutFn(torch.autograd.Function):
     """keras Dropout as a layer: y = x * keep / (1 - rate), mask from the counter hash on the flat element index; the backward is
     the same map on dy (chb_dropout_f32)."""

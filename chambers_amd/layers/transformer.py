@@ -72,9 +72,10 @@ class EncoderLayer(Layer):
                                          (keys.get("mlp") or _next_key(self._site + 1)) if rate else 0).reshape(b, t, d)
 
     def call(self, inputs, mask=None, training=None, keys=None, **kwargs):
-        if mask is not None:
-            raise ValueError("attention masks are not on the ViT path")
         keys = keys or {}
+        if mask is not None:
+            # layers/transformer.py:65-68: self-attention with mask=[mask, mask] (a padding mask over the sequence)
+            return self._call_masked(inputs, mask, training, keys)
         rate = self.dense_dropout_rate if training else 0.0
         x = inputs
         if x.dtype != torch.float32:
@@ -87,6 +88,18 @@ class EncoderLayer(Layer):
             return AG.CastF32Fn.apply(self.norm2(y))
         x_mid = self._attention_branch(self.norm1(x), x, training, keys, rate)
         return self._mlp_branch(self.norm2(x_mid), x_mid, keys, rate)
+
+    def _call_masked(self, x, mask, training, keys):
+        """The block with a sequence mask: the same composition from the stand-alone sub-layers (attention through the general kernel)."""
+        rate = self.dense_dropout_rate if training else 0.0
+        x = x if x.dtype == torch.float32 else x.to(torch.float32)
+        attn = lambda h: self.dropout1(self.multi_head_attention([h, h, h], mask=[mask, mask], training=training, key=keys.get("attn")),   # noqa: E731
+                                       training=training, key=keys.get("proj"))
+        if self.pre_norm:
+            x_mid = AG.AddFn.apply(x, attn(self.norm1(x)))
+            return self._mlp_branch(self.norm2(x_mid), x_mid, keys, rate)
+        x1 = self.norm1(AG.AddFn.apply(x, attn(x)))
+        return AG.CastF32Fn.apply(self.norm2(self._mlp_branch(x1, x1, keys, rate)))
 
     def get_config(self):
         config = {"embed_dim": self.embed_dim, "num_heads": self.num_heads, "ff_dim": self.ff_dim,

@@ -185,6 +185,21 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
                       int H, int hd, float drop_rate, uint32_t drop_key, float* dbias_qkv, float* dbias_ws,
                       const uint32_t* drop_bits, void* stream);
 
+/* General attention: the rest of the ScaledAttention / MultiHeadAttention call signature, which the ViT never exercises
+ * (layers/attention.py:99-153: `mask=[query_mask, value_mask]`, `causal=True`, cross-attention inputs [q, v, k] with Tq != Tv; keras
+ * Attention: scores -= 1e9 * (1 - mask), mask = value_mask AND causal lower triangle; dropout on the weights; output *= query_mask).
+ * q bf16 [B*Tq, ldq], k / v bf16 [B*Tk, ldk / ldv], head h in columns [h*hd, (h+1)*hd); o bf16 [B*Tq, ldo]; lse fp32 [B, H, Tq];
+ * value_mask uint8 [B, Tk], query_mask uint8 [B, Tq] (NULL = all ones).  hd even and <= 128, Tk <= 4096.  Off the hot path: one wave
+ * per query row, fp32 arithmetic (the ViT block uses chb_attention_fwd / _bwd).  Backward: dq fp32 [B*Tq, H*hd] written; dk, dv fp32
+ * [B*Tk, H*hd] ACCUMULATED with atomics (the caller zeroes them). */
+int chb_attention_general_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                              float* lse, int B, int Tq, int Tk, int H, int hd, const uint8_t* value_mask, const uint8_t* query_mask,
+                              int causal, float drop_rate, uint32_t drop_key, void* stream);
+int chb_attention_general_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
+                              const void* d_o, int64_t ldg, const float* lse, float* dq, float* dk, float* dv, int B, int Tq, int Tk, int H,
+                              int hd, const uint8_t* value_mask, const uint8_t* query_mask, int causal, float drop_rate, uint32_t drop_key,
+                              void* stream);
+
 /* ---------------------------------------------------------------- input side */
 #define CHB_DT_U8 0
 #define CHB_DT_F32 1

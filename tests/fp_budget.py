@@ -53,16 +53,29 @@ def cancellation(a, b):
 
 
 def attention_kappas(q, k, v, o, do, keep=None, inv_keep=1.0):
-    """Cancellation ratios of the three products of the attention backward whose left operand the build rounds to bf16
-    (csrc/attention.hip: dS for dQ and dK, the dropped probabilities for dV); q, k, v, o, do: [B, H, N, hd] fp32 oracle tensors."""
+    """Cancellation ratios of the attention backward (csrc/attention.hip); q, k, v, o, do: [B, H, N, hd] fp32 oracle tensors.
+      dq, dk: dS rounded to bf16 element-wise in front of dS.K / dS^T.Q;  dv: the dropped probabilities in front of P^T.dO;
+      dq also: delta_i = sum_d dO_id O_id is formed from the STORED bf16 O and dO (two roundings per term).  An error e_i of
+      delta_i shifts the whole row dS_i. by -P_i. e_i - coherently over the keys - so dQ_i moves by -e_i (P K)_i, while the same
+      errors enter dK_j = sum_i dS_ij Q_i with independent signs.  RMS e_i = FLOOR * sqrt(2 sum_d (dO_id O_id)^2), hence
+      kappa_delta = sqrt(sum_i 2 sum_d (dO_id O_id)^2 ||(P K)_i||^2) / ||dS K||.
+    (Measured on MI355X at the BASELINE geometries: kappa of the dS rounding is 0.9-1.3 - there is NO cancellation blow-up in dS.K,
+    an error-compensated dS would buy nothing; kappa_delta is what sets dQ apart from dK / dV.)"""
     scale = 1.0 / math.sqrt(q.shape[-1])
+    q, k, v, o, do = (t.double() for t in (q, k, v, o, do))
     p = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * scale, dim=-1)
     keepc = keep.to(p.dtype) * inv_keep if keep is not None else 1.0
     delta = (do * o).sum(dim=-1, keepdim=True)
     dp = torch.matmul(do, v.transpose(-1, -2))
     ds = p * (dp * keepc - delta)
     pd = p * keepc
-    return {"dq": cancellation(ds, k), "dk": cancellation(ds.transpose(-1, -2), q), "dv": cancellation(pd.transpose(-1, -2), do)}
+    dq = torch.matmul(ds, k)
+    e2 = 2.0 * ((do * o) ** 2).sum(dim=-1)                        # [B, H, N]: variance of delta_i in units of FLOOR^2
+    pk2 = (torch.matmul(p, k) ** 2).sum(dim=-1)                    # ||(P K)_i||^2
+    kappa_delta = float(torch.sqrt((e2 * pk2).sum()) / (dq.norm() + 1e-300))
+    k_ds = cancellation(ds, k)
+    return {"dq": math.sqrt(k_ds * k_ds + kappa_delta * kappa_delta), "dq_rounding_of_dS": k_ds, "dq_delta": kappa_delta,
+            "dk": cancellation(ds.transpose(-1, -2), q), "dv": cancellation(pd.transpose(-1, -2), do)}
 
 
 def budget_for_row(row, depth, kappa=None):
