@@ -301,3 +301,120 @@ def test_attention_and_encoder_layer_are_differentiable(pre_norm):
         if k.endswith("b_key"):
             continue
         assert rel_l2(v.grad, p["blk/" + k].grad) < B_GRAD_EMU, k
+
+
+# ------------------------------------------------------------------------------------------------ masks / causal / cross-attention
+def _keras_attention(q, k, v, vmask=None, qmask=None, causal=False, keep=None, inv_keep=1.0):
+    """keras Attention (BaseDenseAttention._apply_scores) under ScaledAttention, in torch fp64: [B, H, T, hd] tensors."""
+    s = torch.matmul(q, k.transpose(-1, -2)) / np.sqrt(q.shape[-1])
+    b, _h, tq, tk = s.shape
+    m = torch.ones(b, 1, tq, tk, dtype=torch.bool, device=s.device)
+    if vmask is not None:
+        m = m & vmask[:, None, None, :].bool()
+    if causal:
+        m = m & torch.tril(torch.ones(tq, tk, dtype=torch.bool, device=s.device))
+    s = s - 1e9 * (~m).to(s.dtype)
+    w = torch.softmax(s, dim=-1)
+    if keep is not None:
+        w = w * keep.to(w.dtype) * inv_keep
+    out = torch.matmul(w, v)
+    if qmask is not None:
+        out = out * qmask[:, None, :, None].to(out.dtype)
+    return out
+
+
+@pytest.mark.parametrize("causal,use_masks,tq,tk,hd,rate", [(False, True, 9, 13, 64, 0.0), (True, False, 12, 12, 32, 0.0), (True, True, 7, 7, 64, 0.0),
+                                                          (False, True, 5, 70, 16, 0.25), (False, False, 6, 11, 128, 0.0)])
+def test_scaled_attention_masks_causal_cross_attention(causal, use_masks, tq, tk, hd, rate):
+    """ScaledAttention with the call arguments the ViT never uses (layers/attention.py:7-23 on keras Attention): value mask, query
+    mask, causal mask, key / value length != query length, head widths other than 64 - forward and every gradient against keras
+    Attention's definition in fp64 (operands are bf16 on both sides)."""
+    from chambers_amd.layers.attention import ScaledAttention
+    g = torch.Generator().manual_seed(31)
+    b, h = 2, 3
+    q = bf(torch.randn(b, h, tq, hd, generator=g)).cuda().requires_grad_(True)
+    k = bf(torch.randn(b, h, tk, hd, generator=g)).cuda().requires_grad_(True)
+    v = bf(torch.randn(b, h, tk, hd, generator=g)).cuda().requires_grad_(True)
+    vmask = qmask = None
+    if use_masks:
+        vmask = (torch.rand(b, tk, generator=g) > 0.3)
+        vmask[:, 0] = True
+        qmask = (torch.rand(b, tq, generator=g) > 0.3)
+    layer = ScaledAttention(key_dim=hd, causal=causal, dropout=rate)
+    key = 0x77
+    out = layer([q, v, k], mask=[qmask, vmask] if use_masks else None, training=rate > 0, key=key)
+    dy = torch.randn(out.shape, generator=g).cuda()
+    out.backward(dy.to(out.dtype))
+    keep, inv_keep = None, 1.0
+    if rate:
+        tk4 = (tk + 3) // 4 * 4
+        keep = torch.from_numpy(rng_ref.keep_mask(b * h * tq * tk4, key, rate)).reshape(b, h, tq, tk4)[..., :tk].cuda()
+        inv_keep = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
+    qr, kr, vr = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    ref = _keras_attention(qr, kr, vr, None if vmask is None else vmask.cuda(), None if qmask is None else qmask.cuda(), causal, keep, inv_keep)
+    ref.backward(bf(dy).double())
+    assert out.shape == (b, h, tq, hd) and rel_l2(out.detach().float(), ref.detach()) < 4e-3            # one bf16 rounding of the output
+    for got, want, name in ((q.grad, qr.grad, "dq"), (k.grad, kr.grad, "dk"), (v.grad, vr.grad, "dv")):
+        assert rel_l2(got.float(), want) < 8e-3, name                                                  # bf16 o enters delta; gradients stored bf16
+    if qmask is not None:
+        assert not bool(out.detach()[~qmask.cuda()[:, None, :].expand(b, h, tq)].any())                # masked queries give zero rows
+
+
+def test_multi_head_attention_cross_attention_with_masks_trains():
+    """MultiHeadAttention.call(inputs=[q, v, k], mask=[query_mask, value_mask]) with different query / memory sequences
+    (layers/attention.py:99-145), causal=False: output and the gradient of every weight against the einsum definition in fp64."""
+    from chambers_amd.layers.attention import MultiHeadAttention
+    g = torch.Generator().manual_seed(37)
+    b, tq, tk, d, heads, hd = 2, 10, 23, 128, 2, 64
+    xq = torch.randn(b, tq, d, generator=g).cuda().requires_grad_(True)
+    mem = torch.randn(b, tk, d, generator=g).cuda().requires_grad_(True)
+    vmask = torch.rand(b, tk, generator=g) > 0.25
+    vmask[:, 0] = True
+    qmask = torch.rand(b, tq, generator=g) > 0.2
+    mha = MultiHeadAttention(head_dim=hd, num_heads=heads, dropout_rate=0.0)
+    mha([xq, mem, mem], mask=[qmask, vmask])
+    names = ["w_query", "b_query", "w_value", "b_value", "w_key", "b_key", "w_projection", "b_projection"]
+    with torch.no_grad():
+        for nm in names:
+            if nm.startswith("b_"):
+                getattr(mha, nm).value.copy_(0.05 * torch.randn(getattr(mha, nm).shape, generator=g))
+    for nm in names:
+        getattr(mha, nm).zero_grad()
+    xq.grad = mem.grad = None
+    out = mha([xq, mem, mem], mask=[qmask, vmask], training=False)
+    dy = torch.randn(out.shape, generator=g).cuda()
+    out.backward(dy)
+    w = {nm: getattr(mha, nm).value.detach().double().requires_grad_(True) for nm in names}
+    xr, mr = bf(xq.detach()).double().requires_grad_(True), bf(mem.detach()).double().requires_grad_(True)
+    rb = lambda t: bf(t.float()).double() + (t - t.detach())            # noqa: E731  value rounded to bf16, gradient straight through
+    query = torch.einsum("btd,dnh->bnth", xr, rb(w["w_query"])) + w["b_query"]
+    value = torch.einsum("btd,dnh->bnth", mr, rb(w["w_value"])) + w["b_value"]
+    keyt = torch.einsum("btd,dnh->bnth", mr, rb(w["w_key"])) + w["b_key"]
+    att = _keras_attention(rb(query), rb(keyt), rb(value), vmask.cuda(), qmask.cuda(), False)
+    ref = torch.einsum("bnth,ndh->btd", rb(att), rb(w["w_projection"])) + w["b_projection"]
+    ref.backward(bf(dy).double())
+    assert out.dtype == torch.float32 and rel_l2(out.detach(), ref.detach()) < 4e-3
+    assert rel_l2(xq.grad, xr.grad) < 1.5e-2 and rel_l2(mem.grad, mr.grad) < 1.5e-2
+    for nm in names:
+        assert rel_l2(getattr(mha, nm).value.grad, w[nm].grad) < 1.5e-2, nm
+    assert mha.compute_mask([xq, mem, mem], mask=[qmask, vmask]) is qmask
+
+
+def test_encoder_layer_with_a_padding_mask():
+    """EncoderLayer.call(x, mask) (layers/transformer.py:53-68: self-attention with mask=[mask, mask]): padded positions do not
+    influence the other positions' outputs, and the layer stays differentiable."""
+    from chambers_amd.layers.transformer import EncoderLayer
+    g = torch.Generator().manual_seed(41)
+    b, t, d = 2, 12, 128
+    layer = EncoderLayer(embed_dim=d, num_heads=2, ff_dim=256, pre_norm=True)
+    x = torch.randn(b, t, d, generator=g).cuda()
+    mask = torch.ones(b, t, dtype=torch.bool)
+    mask[:, 9:] = False
+    y1 = layer(x, mask=mask, training=False)
+    x2 = x.clone()
+    x2[:, 9:] = torch.randn(b, 3, d, generator=g).cuda() * 5.0        # change only the padded positions
+    y2 = layer(x2, mask=mask, training=False)
+    assert torch.allclose(y1[:, :9].detach(), y2[:, :9].detach(), rtol=0, atol=0)
+    xg = x.clone().requires_grad_(True)
+    layer(xg, mask=mask, training=False)[:, :9].sum().backward()
+    assert xg.grad is not None and float(xg.grad[:, :9].abs().sum()) > 0 and layer.dense1.kernel.value.grad is not None
