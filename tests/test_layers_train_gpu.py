@@ -386,7 +386,7 @@ def test_multi_head_attention_cross_attention_with_masks_trains():
     out.backward(dy)
     w = {nm: getattr(mha, nm).value.detach().double().requires_grad_(True) for nm in names}
     xr, mr = bf(xq.detach()).double().requires_grad_(True), bf(mem.detach()).double().requires_grad_(True)
-    rb = lambda t: bf(t.float()).double() + (t - t.detach())            # noqa: E731  value rounded to bf16, gradient straight through
+    rb = lambda t: bf(t.detach().float()).double() + (t - t.detach())   # noqa: E731  value rounded to bf16, gradient straight through (once)
     query = torch.einsum("btd,dnh->bnth", xr, rb(w["w_query"])) + w["b_query"]
     value = torch.einsum("btd,dnh->bnth", mr, rb(w["w_value"])) + w["b_value"]
     keyt = torch.einsum("btd,dnh->bnth", mr, rb(w["w_key"])) + w["b_key"]
