@@ -9,8 +9,8 @@ get_weights()/set_weights().  Execution goes through the whole-model HIP engine 
 `pooling` ('cls' | 'avg' | 'max' | 'sum' | None), `feature_dim` (tanh head) and `include_top` follow :172-191,272-283.
 `DistilledVisionTransformer` / `DeiTS16` / `DeiTB16` (:295-400, :583-652) add the distillation token and its head.
 The pretrained-weight names, default sizes and the feature-layer rule follow :99-128; the download itself is not built
-(`weights="imagenet21k+_224"` needs network + .h5): such a name resolves to a local cache file (`_load_weights`), and
-`weights` may also be None or a path to an .npz of Keras-named arrays."""
+(`weights="imagenet21k+_224"` needs the network): such a name resolves to the release's `.h5` in a local cache (`_load_weights`),
+and `weights` may also be None or a path to a Keras `.h5` weight file (read by chambers_amd.utils.hdf5_lite) or an `.npz`."""
 import os
 
 import numpy as np
@@ -65,18 +65,19 @@ def _weights_cache_dir():
 
 
 def _load_weights(model, weights, include_top):
-    """vision_transformer.py:149-169 without the download: a pretrained name resolves to `<model>_<suffix>[_no_top]` in the local
-    cache ($CHB_WEIGHTS_DIR, else ~/.keras/models - where keras `get_file` would have put it), as `.npz` of Keras-named arrays
-    (this image has no HDF5 reader: convert the release's `.h5` once with h5py elsewhere); any other string is a path."""
+    """vision_transformer.py:149-169 without the download: a pretrained name resolves to `<model>_<suffix>[_no_top].h5` in the local
+    cache ($CHB_WEIGHTS_DIR, else ~/.keras/models - where keras `get_file` would have put the release file), read by the pure-Python
+    HDF5 reader (chambers_amd.utils.hdf5_lite); a `.npz` of Keras-named arrays with the same stem is accepted too; any other string
+    is a path to an `.h5` / `.npz` file."""
     if _are_weights_pretrained(weights, model.name):
         stem = model.name + "_" + _WEIGHT_SUFFIXES[model.name][weights] + ("" if include_top else "_no_top")
-        path = os.path.join(_weights_cache_dir(), stem + ".npz")
-        if not os.path.exists(path):
-            h5 = os.path.join(_weights_cache_dir(), stem + ".h5")
+        cands = [os.path.join(_weights_cache_dir(), stem + ext) for ext in (".h5", ".npz")]
+        path = next((c for c in cands if os.path.exists(c)), None)
+        if path is None:
             raise RuntimeError("pretrained weights %r of %s: the reference downloads %s.h5 from its GitHub release (vision_transformer.py:"
-                               "149-167); this build has no network path and no HDF5 reader - put %s.npz (Keras-named arrays) into %s%s, "
-                               "or pass weights=None / a path to such an .npz / use Model.load_timm_state_dict"
-                               % (weights, model.name, stem, stem, _weights_cache_dir(), " (found %s, not readable here)" % h5 if os.path.exists(h5) else ""))
+                               "149-167); this build has no network path - put that file (or %s.npz of Keras-named arrays) into %s, "
+                               "or pass weights=None / a path to an .h5 or .npz file / use Model.load_timm_state_dict"
+                               % (weights, model.name, stem, stem, _weights_cache_dir()))
         model.load_weights(path)
     elif weights is not None:
         if not os.path.exists(str(weights)):
@@ -217,8 +218,37 @@ class Model(Layer):
         self._bump()
 
     def load_weights(self, path):
+        """keras Model.load_weights for the two file kinds this build reads: `.npz` of Keras-named arrays (what save_weights
+        writes here) and Keras' own `.h5` / `.hdf5` weight files (the reference's pretrained releases, vision_transformer.py:149-169),
+        read by the pure-Python HDF5 subset reader chambers_amd.utils.hdf5_lite (this image has no h5py)."""
+        path = str(path)
+        if path.endswith((".h5", ".hdf5", ".keras.h5")):
+            self._load_keras_h5(path)
+            return
         with np.load(path) as z:
             self.assign_keras_weights({k: z[k] for k in z.files})
+
+    def _load_keras_h5(self, path):
+        """keras hdf5_format.load_weights_from_hdf5_group (topological loading): the file's layers that have weights are matched IN
+        ORDER with the model's layers that have weights, and each layer's arrays in the order of its `weight_names` with the layer's
+        `weights` - names are not compared, counts and shapes are."""
+        from ...utils.hdf5_lite import load_keras_weights
+        self._sync()
+        values, layout = load_keras_weights(path)
+        file_layers = [(lname, names) for lname, names in layout if names]
+        mine = [l for l in self._layers if l.weights]
+        if len(file_layers) != len(mine):
+            raise ValueError("You are trying to load a weight file containing %d layers into a model with %d layers."
+                             % (len(file_layers), len(mine)))
+        for (lname, names), layer in zip(file_layers, mine):
+            ws = layer.weights
+            if len(names) != len(ws):
+                raise ValueError('Layer #%s (named "%s" in the current model) was found to correspond to layer %s in the save file. '
+                                 "However the new layer %s expects %d weights, but the saved weights have %d elements."
+                                 % (self._layers.index(layer), layer.name, lname, layer.name, len(ws), len(names)))
+            layer.set_weights([values[n] for n in names])
+        self._dirty = None
+        self._bump()
 
     def load_timm_state_dict(self, state_dict):
         """Import a timm ViT `state_dict()` (or any name -> array mapping with timm's keys) through the conversion rules of
