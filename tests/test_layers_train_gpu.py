@@ -396,7 +396,8 @@ def test_multi_head_attention_cross_attention_with_masks_trains():
     assert out.dtype == torch.float32 and rel_l2(out.detach(), ref.detach()) < 4e-3
     assert rel_l2(xq.grad, xr.grad) < 1.5e-2 and rel_l2(mem.grad, mr.grad) < 1.5e-2
     for nm in names:
-        assert rel_l2(getattr(mha, nm).value.grad, w[nm].grad) < 1.5e-2, nm
+        if nm != "b_key":          # exactly zero in exact arithmetic (softmax shift invariance): noise against noise
+            assert rel_l2(getattr(mha, nm).value.grad, w[nm].grad) < 1.5e-2, nm
     assert mha.compute_mask([xq, mem, mem], mask=[qmask, vmask]) is qmask
 
 
