@@ -873,56 +873,6 @@ __global__ void __launch_bounds__(256) normalize_patchify_kernel(const uint8_t* 
     }
 }
 
-// The same with the patch runs staged through LDS (patch % 16 == 0; see fused_final_kernel): workgroup = 16 image rows of one image,
-// every patch's 16 rows x patch pixels leave as one contiguous run of 16-byte stores.
-template <int MODE>
-__global__ void __launch_bounds__(256) normalize_patchify_staged_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int H, int W, int P,
-                                                                        int gh, int gw, NormConst nc) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t np_stage[];
-    const int n = blockIdx.y, y0 = blockIdx.x * 16;
-    const int wq = (gw * P) >> 2;
-    const int K = P * P * 3;
-    for (int idx = threadIdx.x; idx < 16 * wq; idx += 256) {
-        const int k = idx / wq, xq = idx - k * wq;
-        const int y = y0 + k, x0 = xq * 4;
-        const uint8_t* s = in + (((int64_t)n * H + y) * W + x0) * 3;
-        uint8_t b[12];
-        if ((W & 3) == 0) {
-            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
-            const uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { b[i] = (uint8_t)(w0 >> (8 * i)); b[4 + i] = (uint8_t)(w1 >> (8 * i)); b[8 + i] = (uint8_t)(w2 >> (8 * i)); }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) b[i] = s[i];
-        }
-        float f[12];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (MODE == 0) {
-                f[3 * p + 0] = norm1<0>(b[3 * p + 2], 0, nc);
-                f[3 * p + 1] = norm1<0>(b[3 * p + 1], 1, nc);
-                f[3 * p + 2] = norm1<0>(b[3 * p + 0], 2, nc);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) f[3 * p + c] = norm1<MODE>(b[3 * p + c], c, nc);
-            }
-        }
-        const int pc = x0 / P;
-        uint2* d = reinterpret_cast<uint2*>(np_stage + ((pc * 16 + k) * P + (x0 - pc * P)) * 6);
-        d[0] = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
-        d[1] = make_uint2(pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
-        d[2] = make_uint2(pack_bf16x2(f[8], f[9]), pack_bf16x2(f[10], f[11]));
-    }
-    __syncthreads();
-    const int upc = 6 * P;
-    char* obase = reinterpret_cast<char*>(out) + (((int64_t)n * gh + y0 / P) * gw * K + (int64_t)(y0 % P) * P * 3) * 2;
-    for (int u = threadIdx.x; u < gw * upc; u += 256) {
-        const int pc = u / upc, w = u - pc * upc;
-        *reinterpret_cast<uint4*>(obase + (int64_t)pc * K * 2 + w * 16) = *reinterpret_cast<const uint4*>(np_stage + (int64_t)u * 16);
-    }
-}
-
 // float32 NHWC (already normalised, the reference model's own input) -> bf16 patch rows
 __global__ void __launch_bounds__(256) patchify_f32_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int B, int H, int W, int P,
                                                            int gh, int gw) {
@@ -1511,16 +1461,10 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
 
 // final pass: grid = (row groups of 16, B); wave = 4 consecutive rows, lane = 4-pixel quad.
 // PATCH: "tf" normalisation + bf16 patch rows (patch % 4 == 0: a quad never straddles patches), else uint8 NHWC
-// PATCH output, staged (patch % 16 == 0, the slab's 16 rows x W pixels of bf16 fit the LDS): the workgroup's 16 image rows are
-// one row of patches (or a 16-row band of it), and inside a patch row-major [p][p][3] those 16 rows are ONE contiguous run of
-// 16 * p * 6 bytes.  The lanes therefore park their 24-byte quads in LDS in destination order and the workgroup then writes every
-// patch's run with full 16-byte-per-lane stores - 1 KiB contiguous per wave-instruction instead of 4-byte pieces 24 bytes apart
-// that reach a 128-byte line from five different lanes (r02: the normalise + patchify pass sat at 55 % of HBM peak for that reason).
 template <int NLEV, bool PATCH, bool LOCAL>
 __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw,
-                                                          int fast, int staged) {
+                                                          int fast) {
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
-    extern __shared__ __attribute__((aligned(16))) uint8_t patch_stage[];
     const int n = blockIdx.y;
     fused_stage_luts(P, n, lutS);
     const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
@@ -1529,32 +1473,6 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
     const int hh = PATCH ? gh * patch : P.H;
     const int row0 = blockIdx.x * 16 + wave * 4;
     const int K = patch * patch * 3;
-    if (PATCH && staged) {
-        // hh is a multiple of 16 here: every wave has its four rows, nobody leaves before the barrier
-        for (int idx = lane; idx < 4 * wq; idx += 64) {
-            const int k = idx / wq, xq = idx - k * wq;
-            const int y = row0 + k, x0 = xq * 4;
-            uint8_t b[12];
-            FusedQuad<NLEV - 1, LOCAL>::at(P, C, y, x0, b);
-            float f[12];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) f[i] = norm1<1>(b[i], i % 3, NormConst{});
-            const int pc = x0 / patch;
-            uint2* d = reinterpret_cast<uint2*>(patch_stage + ((pc * 16 + (y & 15)) * patch + (x0 - pc * patch)) * 6);
-            d[0] = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
-            d[1] = make_uint2(pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
-            d[2] = make_uint2(pack_bf16x2(f[8], f[9]), pack_bf16x2(f[10], f[11]));
-        }
-        __syncthreads();
-        const int y0 = blockIdx.x * 16;
-        const int upc = 6 * patch;                                   // 16-byte units per patch run (16 rows x patch pixels x 6 bytes)
-        char* obase = reinterpret_cast<char*>(out) + (((int64_t)n * gh + y0 / patch) * gw * K + (int64_t)(y0 % patch) * patch * 3) * 2;
-        for (int u = threadIdx.x; u < gw * upc; u += 256) {
-            const int pc = u / upc, w = u - pc * upc;
-            *reinterpret_cast<uint4*>(obase + (int64_t)pc * K * 2 + w * 16) = *reinterpret_cast<const uint4*>(patch_stage + (int64_t)u * 16);
-        }
-        return;
-    }
     if (row0 >= hh) return;
     const int nrows = min(4, hh - row0);
     // the wave's 4 rows x wq quads as one index space: all 64 lanes busy whatever the row length
@@ -1805,16 +1723,10 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
     int gh = 0, gw = 0;
     if (patch) { gh = H / patch; gw = W / patch; }
     const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);
-    // staged patch rows: 16 rows x (gw * patch) pixels of bf16 in LDS beside the 3 KiB of tables; CHB_FUSED_STAGE=0 (A/B) = direct stores
-    static const int stage_env = getenv("CHB_FUSED_STAGE") ? atoi(getenv("CHB_FUSED_STAGE")) : 1;
-    const size_t stage_bytes = (size_t)16 * gw * patch * 6;
-    const int staged = (patch && stage_env && (patch & 15) == 0 && stage_bytes + sizeof(uint8_t) * CHB_FUSED_MAX_OPS * 768 <= 64 * 1024 &&
-                        !((uintptr_t)dst & 15)) ? 1 : 0;
-    const size_t dyn = staged ? stage_bytes : 0;
 #define CHB_FUSED_FINAL2(NL, PT)                                                                                                   \
     do {                                                                                                                           \
-        if (local) hipLaunchKernelGGL((fused_final_kernel<NL, PT, true>), grid, dim3(256), dyn, s, src, dst, P, patch, gh, gw, fast, staged);  \
-        else hipLaunchKernelGGL((fused_final_kernel<NL, PT, false>), grid, dim3(256), dyn, s, src, dst, P, patch, gh, gw, fast, staged);       \
+        if (local) hipLaunchKernelGGL((fused_final_kernel<NL, PT, true>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);  \
+        else hipLaunchKernelGGL((fused_final_kernel<NL, PT, false>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);       \
     } while (0)
 #define CHB_FUSED_FINAL(NL)                \
     do {                                   \
@@ -1957,17 +1869,6 @@ int chb_normalize_patchify_bf16(const uint8_t* in, void* out, int B, int H, int 
     const int grid = stream_grid(total);
     hipStream_t s = (hipStream_t)stream;
     bf16_t* o = (bf16_t*)out;
-    const size_t stage_bytes = (size_t)16 * gw * patch * 6;
-    static const int stage_env = getenv("CHB_FUSED_STAGE") ? atoi(getenv("CHB_FUSED_STAGE")) : 1;
-    if (stage_env && (patch & 15) == 0 && stage_bytes <= 60 * 1024 && !((uintptr_t)out & 15) && B <= 65535 && (!(W & 3) ? !((uintptr_t)in & 3) : true)) {
-        const dim3 g2(gh * patch / 16, B);
-        if (mode == CHB_NORM_TF) hipLaunchKernelGGL(normalize_patchify_staged_kernel<1>, g2, dim3(256), stage_bytes, s, in, o, H, W, patch, gh, gw, kCaffe);
-        else if (mode == CHB_NORM_CAFFE) hipLaunchKernelGGL(normalize_patchify_staged_kernel<0>, g2, dim3(256), stage_bytes, s, in, o, H, W, patch, gh, gw, kCaffe);
-        else if (mode == CHB_NORM_TORCH) hipLaunchKernelGGL(normalize_patchify_staged_kernel<2>, g2, dim3(256), stage_bytes, s, in, o, H, W, patch, gh, gw, kTorch);
-        else return CHB_EINVAL;
-        CHB_LAUNCH_CHECK();
-        return CHB_OK;
-    }
     if (mode == CHB_NORM_TF) hipLaunchKernelGGL(normalize_patchify_kernel<1>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
     else if (mode == CHB_NORM_CAFFE) hipLaunchKernelGGL(normalize_patchify_kernel<0>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
     else if (mode == CHB_NORM_TORCH) hipLaunchKernelGGL(normalize_patchify_kernel<2>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kTorch);
