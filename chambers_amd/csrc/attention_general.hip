@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "../../include/chambers_hip.h"
 #include <math.h>
+#include <atomic>
 
 namespace {
 
@@ -166,11 +167,11 @@ int chb_attention_general_fwd(const void* q, int64_t ldq, const void* k, int64_t
     GaParams p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, B, Tq, Tk, H, hd, value_mask, query_mask, causal,
                1.0f / sqrtf((float)hd), 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key};
     const size_t lds = (size_t)4 * (GA_MAX_HD + Tk) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<bool> attr{false};        // once per process: a driver call, not per launch
+    if (!attr.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)ga_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (GA_MAX_HD + GA_MAX_TK) * 4) != hipSuccess)
             return CHB_ELAUNCH;
-        attr = true;
+        attr.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ga_fwd_kernel, dim3(B * H, chb_div_up(Tq, 4)), dim3(256), lds, (hipStream_t)stream, p, (bf16_t*)o, ldo, lse);
     CHB_LAUNCH_CHECK();
@@ -188,11 +189,11 @@ int chb_attention_general_bwd(const void* q, int64_t ldq, const void* k, int64_t
     GaParams p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, B, Tq, Tk, H, hd, value_mask, query_mask, causal,
                1.0f / sqrtf((float)hd), 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key};
     const size_t lds = (size_t)4 * (2 * GA_MAX_HD + 2 * Tk) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<bool> attr{false};
+    if (!attr.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)ga_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (2 * GA_MAX_HD + 2 * GA_MAX_TK) * 4) != hipSuccess)
             return CHB_ELAUNCH;
-        attr = true;
+        attr.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(ga_bwd_kernel, dim3(B * H, chb_div_up(Tq, 4)), dim3(256), lds, (hipStream_t)stream, p, (const bf16_t*)o, ldo,
                        (const bf16_t*)d_o, ldg, lse, dq, dk, dv);

@@ -10,8 +10,11 @@ outputs, gelu(a) and gelu'(a), bf16 dY operands in backward.  No Function falls 
 
 Layer variables are leaf tensors with requires_grad (chambers_amd/_keras_like.Variable); after `loss.backward()` the gradients
 are in `variable.value.grad`, and `chambers_amd.optimizers.AdamW.apply_gradients` consumes them."""
+import ctypes
+
 import torch
 
+from .. import _lib
 from .. import kernels as K
 
 
@@ -343,25 +346,19 @@ class ConcatTokensFn(torch.autograd.Function):
         e = emb.detach()
         e = (K.cast_bf16(e) if xx.dtype == torch.bfloat16 else e).contiguous()
         b = xx.shape[0]
-        eb = e.unsqueeze(0).expand(b, *e.shape)
-        # the embedding rows are read with stride 0 over the batch: concat_axis1 copies rows, no arithmetic
         ctx.left, ctx.ne, ctx.x_shape = bool(left), int(e.shape[0]), x.shape
-        import ctypes
-        from .. import _lib
         n, d = int(xx.shape[1]), int(xx.shape[2])
         es = xx.element_size()
         out = torch.empty((b, n + ctx.ne, d), dtype=xx.dtype, device=xx.device)
         e_at, x_at = (0, ctx.ne) if left else (n, 0)
         row = (n + ctx.ne) * d * es
+        # the embedding rows are read with stride 0 over the batch: strided row copies, no arithmetic
         _lib.call("chb_copy_rows", _lib.ptr(e), 0, ctypes.c_void_p(out.data_ptr() + e_at * d * es), row, b, ctx.ne * d * es, K._s())
         _lib.call("chb_copy_rows", _lib.ptr(xx), n * d * es, ctypes.c_void_p(out.data_ptr() + x_at * d * es), row, b, n * d * es, K._s())
-        del eb
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        import ctypes
-        from .. import _lib
         b, n, d = (int(s) for s in ctx.x_shape)
         ne = ctx.ne
         dyf = K.cast_f32(dy).contiguous()
@@ -383,8 +380,6 @@ class TakeTokenFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, index):
-        import ctypes
-        from .. import _lib
         xx = x.detach().contiguous()
         b, n, d = (int(s) for s in xx.shape)
         es = xx.element_size()
@@ -395,8 +390,6 @@ class TakeTokenFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        import ctypes
-        from .. import _lib
         b, n, d = ctx.shape
         dyc = dy.contiguous()
         es = dyc.element_size()

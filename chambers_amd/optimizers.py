@@ -59,7 +59,8 @@ class AdamW:
         t = step + 1
         b1, b2 = np.float32(self.beta_1), np.float32(self.beta_2)
         lr_t = float(lr * np.sqrt(np.float32(1.0) - np.power(b2, np.float32(t))) / (np.float32(1.0) - np.power(b1, np.float32(t))))
-        slots = self.__dict__.setdefault("_slots", {})
+        import weakref
+        slots = self.__dict__.setdefault("_slots", weakref.WeakKeyDictionary())     # Adam moments per variable, dropped with it
         for grad, var in grads_and_vars:
             g = var.value.grad if grad is None else grad
             if g is None:
@@ -67,9 +68,9 @@ class AdamW:
             p = var.value.detach()
             n = p.numel()
             n4 = (n + 3) // 4 * 4
-            st = slots.get(id(var))
+            st = slots.get(var)
             if st is None:
-                st = slots[id(var)] = (torch.zeros(n4, dtype=torch.float32, device=p.device), torch.zeros(n4, dtype=torch.float32, device=p.device))
+                st = slots[var] = (torch.zeros(n4, dtype=torch.float32, device=p.device), torch.zeros(n4, dtype=torch.float32, device=p.device))
             if n4 != n or not p.is_contiguous():          # odd sizes: update a padded copy (chb_adamw works on float4)
                 pp = torch.zeros(n4, dtype=torch.float32, device=p.device)
                 pp[:n] = p.reshape(-1)

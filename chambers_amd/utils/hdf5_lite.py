@@ -10,8 +10,6 @@ Exactly that subset is implemented, from the HDF5 File Format Specification (ver
 datasets, version-2 object headers / dense groups, variable-length data) raises NotImplementedError naming the feature.
 Validated against files written by h5py 3.3 / libhdf5 1.10.6 (tests/golden/keras_weights_*.h5, made by tests/golden/make_h5_golden.py).
 """
-import struct
-
 import numpy as np
 
 _SIG = b"\x89HDF\r\n\x1a\n"
