@@ -839,20 +839,34 @@ __global__ void __launch_bounds__(256) normalize_u8x4_kernel(const uint8_t* __re
 template <int MODE>
 __global__ void __launch_bounds__(256) normalize_patchify_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int B, int H,
                                                                  int W, int P, int gh, int gw, NormConst nc) {
+    // grid = (groups of 16 image rows, B); wave = 4 consecutive rows, lane = 4-pixel quad - as fused_final_kernel, and like it without
+    // integer division in the loop (r03: the flat 64-bit quad index cost eight divisions per quad, more than the conversion itself)
     const int wq = (gw * P) >> 2;
     const int hh = gh * P;
-    const int64_t total = (int64_t)B * hh * wq;
     const int K = P * P * 3;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-        const int xq = (int)(q % wq);
-        const int64_t r = q / wq;
-        const int y = (int)(r % hh);
-        const int n = (int)(r / hh);
-        const int x0 = xq * 4;
+    const int n = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * 16 + wave * 4;
+    if (row0 >= hh) return;
+    const int nrows = min(4, hh - row0);
+    const int ps = ((P & (P - 1)) == 0) ? (31 - __builtin_clz(P)) : -1;
+    const bool dw = ((W & 3) == 0) && !((uintptr_t)in & 3);          // 12-byte quads are dword-aligned: three dword loads instead of twelve byte loads
+    int k = 0, xq = lane;
+    while (xq >= wq) { xq -= wq; ++k; }
+    const int adv_k = 64 / wq, adv_x = 64 - adv_k * wq;
+    for (; k < nrows; ) {
+        const int y = row0 + k, x0 = xq * 4;
         const uint8_t* s = in + (((int64_t)n * H + y) * W + x0) * 3;
         uint8_t b[12];
+        if (dw) {
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+            const uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) b[i] = s[i];
+            for (int i = 0; i < 4; ++i) { b[i] = (uint8_t)(w0 >> (8 * i)); b[4 + i] = (uint8_t)(w1 >> (8 * i)); b[8 + i] = (uint8_t)(w2 >> (8 * i)); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = s[i];
+        }
         float f[12];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -865,11 +879,17 @@ __global__ void __launch_bounds__(256) normalize_patchify_kernel(const uint8_t* 
                 for (int c = 0; c < 3; ++c) f[3 * p + c] = norm1<MODE>(b[3 * p + c], c, nc);
             }
         }
-        const int64_t row = ((int64_t)n * gh + y / P) * gw + x0 / P;
-        const int col = ((y % P) * P + (x0 % P)) * 3;
+        int py, px, ry, rx;
+        if (ps >= 0) { py = y >> ps; px = x0 >> ps; ry = y & (P - 1); rx = x0 & (P - 1); }
+        else { py = y / P; px = x0 / P; ry = y - py * P; rx = x0 - px * P; }
+        const int64_t row = ((int64_t)n * gh + py) * gw + px;
+        const int col = (ry * P + rx) * 3;
         uint32_t* d = reinterpret_cast<uint32_t*>(out + row * K + col);
 #pragma unroll
         for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+        k += adv_k;
+        xq += adv_x;
+        if (xq >= wq) { xq -= wq; ++k; }
     }
 }
 
@@ -1426,10 +1446,18 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
     const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
     const int wq = (P.W + 3) >> 2;
     const int nq = P.H * wq;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-        const int y = q / wq, x0 = (q - y * wq) * 4;
+    // (row, quad) advance by the grid stride without a division per quad: one division per thread up front
+    const int stride = gridDim.x * blockDim.x;
+    const int adv_y = stride / wq, adv_x = stride - adv_y * wq;
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = q / wq, xq = q - y * wq;
+    for (; q < nq; q += stride) {
+        const int x0 = xq * 4;
         uint8_t b[12];
         FusedQuad<NLEV - 1, LOCAL>::at(P, C, y, x0, b);
+        y += adv_y;
+        xq += adv_x;
+        if (xq >= wq) { xq -= wq; ++y; }
         if (minmax) {
 #pragma unroll
             for (int i = 0; i < 12; ++i)
@@ -1475,9 +1503,15 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
     const int K = patch * patch * 3;
     if (row0 >= hh) return;
     const int nrows = min(4, hh - row0);
-    // the wave's 4 rows x wq quads as one index space: all 64 lanes busy whatever the row length
-    for (int idx = lane; idx < nrows * wq; idx += 64) {
-        const int k = idx / wq, xq = idx - k * wq;
+    // The wave's 4 rows x wq quads as one index space: all 64 lanes busy whatever the row length.  No integer division in the loop
+    // (r03: five of them per quad - idx / wq and the patch coordinates - cost more vector instructions than a pixel-local chain
+    // itself): (row, quad) advance by 64 quads per trip, and a power-of-two patch edge (16, 32: every ViT of the zoo) turns the patch
+    // coordinates into shifts and masks; other edges keep the division.
+    const int ps = (PATCH && (patch & (patch - 1)) == 0) ? (31 - __builtin_clz(patch)) : -1;     // uniform
+    int k = 0, xq = lane;
+    while (xq >= wq) { xq -= wq; ++k; }
+    const int adv_k = 64 / wq, adv_x = 64 - adv_k * wq;       // 64 quads = adv_k whole rows + adv_x quads (uniform, once per wave)
+    for (; k < nrows; ) {
         const int y = row0 + k, x0 = xq * 4;
         uint8_t b[12];
         FusedQuad<NLEV - 1, LOCAL>::at(P, C, y, x0, b);
@@ -1485,8 +1519,11 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
             float f[12];
 #pragma unroll
             for (int i = 0; i < 12; ++i) f[i] = norm1<1>(b[i], i % 3, NormConst{});
-            const int64_t row = ((int64_t)n * gh + y / patch) * gw + x0 / patch;
-            const int col = ((y % patch) * patch + (x0 % patch)) * 3;
+            int py, px, ry, rx;
+            if (ps >= 0) { py = y >> ps; px = x0 >> ps; ry = y & (patch - 1); rx = x0 & (patch - 1); }
+            else { py = y / patch; px = x0 / patch; ry = y - py * patch; rx = x0 - px * patch; }
+            const int64_t row = ((int64_t)n * gh + py) * gw + px;
+            const int col = (ry * patch + rx) * 3;
             uint32_t* d = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(out) + row * K + col);
 #pragma unroll
             for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
@@ -1495,6 +1532,9 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
             if (C.fast) store_quad<true>(orow, x0, P.W, b);
             else store_quad<false>(orow, x0, P.W, b);
         }
+        k += adv_k;
+        xq += adv_x;
+        if (xq >= wq) { xq -= wq; ++k; }
     }
 }
 
@@ -1865,13 +1905,13 @@ int chb_normalize_patchify_bf16(const uint8_t* in, void* out, int B, int H, int 
     if (!in || !out || B < 0 || H <= 0 || W <= 0 || patch <= 0 || (patch & 3)) return CHB_EINVAL;
     const int gh = H / patch, gw = W / patch;
     if (gh == 0 || gw == 0) return CHB_EINVAL;
-    const int64_t total = (int64_t)B * gh * patch * ((gw * patch) / 4);
-    const int grid = stream_grid(total);
     hipStream_t s = (hipStream_t)stream;
     bf16_t* o = (bf16_t*)out;
-    if (mode == CHB_NORM_TF) hipLaunchKernelGGL(normalize_patchify_kernel<1>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
-    else if (mode == CHB_NORM_CAFFE) hipLaunchKernelGGL(normalize_patchify_kernel<0>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
-    else if (mode == CHB_NORM_TORCH) hipLaunchKernelGGL(normalize_patchify_kernel<2>, dim3(grid), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kTorch);
+    if (B > 65535) return CHB_EUNSUPPORTED;
+    const dim3 g2((gh * patch + 15) / 16, B);
+    if (mode == CHB_NORM_TF) hipLaunchKernelGGL(normalize_patchify_kernel<1>, g2, dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
+    else if (mode == CHB_NORM_CAFFE) hipLaunchKernelGGL(normalize_patchify_kernel<0>, g2, dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
+    else if (mode == CHB_NORM_TORCH) hipLaunchKernelGGL(normalize_patchify_kernel<2>, g2, dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kTorch);
     else return CHB_EINVAL;
     CHB_LAUNCH_CHECK();
     return CHB_OK;
