@@ -836,59 +836,77 @@ __global__ void __launch_bounds__(256) normalize_u8x4_kernel(const uint8_t* __re
 // Normalise (mode tf/torch/caffe) + patchify: uint8 NHWC -> bf16 [B*gh*gw, p*p*3] rows, the
 // A operand of the patch-embedding GEMM (vision_transformer.py:235-248 Conv2D k=s=p 'valid' is
 // a pure gather for NHWC input).  One thread = 4 pixels of one image row (p % 4 == 0).
+// one quad: 12 normalised values -> 24 bytes of its patch row
 template <int MODE>
+__device__ __forceinline__ void np_store_quad(const uint32_t (&w)[3], bf16_t* __restrict__ out, int n, int y, int x0, int P, int ps, int gh, int gw,
+                                              int K, const NormConst& nc) {
+    uint8_t b[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b[i] = (uint8_t)(w[0] >> (8 * i)); b[4 + i] = (uint8_t)(w[1] >> (8 * i)); b[8 + i] = (uint8_t)(w[2] >> (8 * i)); }
+    float f[12];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (MODE == 0) {
+            f[3 * p + 0] = norm1<0>(b[3 * p + 2], 0, nc);
+            f[3 * p + 1] = norm1<0>(b[3 * p + 1], 1, nc);
+            f[3 * p + 2] = norm1<0>(b[3 * p + 0], 2, nc);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) f[3 * p + c] = norm1<MODE>(b[3 * p + c], c, nc);
+        }
+    }
+    int py, px, ry, rx;
+    if (ps >= 0) { py = y >> ps; px = x0 >> ps; ry = y & (P - 1); rx = x0 & (P - 1); }
+    else { py = y / P; px = x0 / P; ry = y - py * P; rx = x0 - px * P; }
+    const int64_t row = ((int64_t)n * gh + py) * gw + px;
+    const int col = (ry * P + rx) * 3;
+    uint2* d = reinterpret_cast<uint2*>(out + row * K + col);          // 24 bytes, 8-byte aligned (col * 2 is a multiple of 24)
+    d[0] = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+    d[1] = make_uint2(pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    d[2] = make_uint2(pack_bf16x2(f[8], f[9]), pack_bf16x2(f[10], f[11]));
+}
+
+__device__ __forceinline__ void np_load_quad(const uint8_t* __restrict__ s, bool dw, uint32_t (&w)[3]) {
+    if (dw) {
+        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+        w[0] = s4[0]; w[1] = s4[1]; w[2] = s4[2];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = (uint32_t)s[4 * i] | ((uint32_t)s[4 * i + 1] << 8) | ((uint32_t)s[4 * i + 2] << 16) | ((uint32_t)s[4 * i + 3] << 24);
+    }
+}
+
+// grid = (groups of 4 * ROWS image rows, B); wave = ROWS consecutive rows, lane = 4-pixel quad.  No integer division in the loop (r03:
+// the flat 64-bit quad index of rounds 1-2 cost eight divisions per quad), and TWO quads per trip: both loads are issued before either
+// is converted, so a wave keeps two rows' worth of requests in flight.
+template <int MODE, int ROWS>
 __global__ void __launch_bounds__(256) normalize_patchify_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int B, int H,
                                                                  int W, int P, int gh, int gw, NormConst nc) {
-    // grid = (groups of 16 image rows, B); wave = 4 consecutive rows, lane = 4-pixel quad - as fused_final_kernel, and like it without
-    // integer division in the loop (r03: the flat 64-bit quad index cost eight divisions per quad, more than the conversion itself)
     const int wq = (gw * P) >> 2;
     const int hh = gh * P;
     const int K = P * P * 3;
     const int n = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int row0 = blockIdx.x * 16 + wave * 4;
+    const int row0 = blockIdx.x * (4 * ROWS) + wave * ROWS;
     if (row0 >= hh) return;
-    const int nrows = min(4, hh - row0);
+    const int nrows = min(ROWS, hh - row0);
     const int ps = ((P & (P - 1)) == 0) ? (31 - __builtin_clz(P)) : -1;
     const bool dw = ((W & 3) == 0) && !((uintptr_t)in & 3);          // 12-byte quads are dword-aligned: three dword loads instead of twelve byte loads
+    const uint8_t* img = in + (int64_t)n * H * W * 3;
     int k = 0, xq = lane;
     while (xq >= wq) { xq -= wq; ++k; }
     const int adv_k = 64 / wq, adv_x = 64 - adv_k * wq;
-    for (; k < nrows; ) {
-        const int y = row0 + k, x0 = xq * 4;
-        const uint8_t* s = in + (((int64_t)n * H + y) * W + x0) * 3;
-        uint8_t b[12];
-        if (dw) {
-            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
-            const uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { b[i] = (uint8_t)(w0 >> (8 * i)); b[4 + i] = (uint8_t)(w1 >> (8 * i)); b[8 + i] = (uint8_t)(w2 >> (8 * i)); }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) b[i] = s[i];
-        }
-        float f[12];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (MODE == 0) {
-                f[3 * p + 0] = norm1<0>(b[3 * p + 2], 0, nc);
-                f[3 * p + 1] = norm1<0>(b[3 * p + 1], 1, nc);
-                f[3 * p + 2] = norm1<0>(b[3 * p + 0], 2, nc);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) f[3 * p + c] = norm1<MODE>(b[3 * p + c], c, nc);
-            }
-        }
-        int py, px, ry, rx;
-        if (ps >= 0) { py = y >> ps; px = x0 >> ps; ry = y & (P - 1); rx = x0 & (P - 1); }
-        else { py = y / P; px = x0 / P; ry = y - py * P; rx = x0 - px * P; }
-        const int64_t row = ((int64_t)n * gh + py) * gw + px;
-        const int col = (ry * P + rx) * 3;
-        uint32_t* d = reinterpret_cast<uint32_t*>(out + row * K + col);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
-        k += adv_k;
-        xq += adv_x;
+    while (k < nrows) {
+        int k2 = k + adv_k, xq2 = xq + adv_x;
+        if (xq2 >= wq) { xq2 -= wq; ++k2; }
+        const bool two = k2 < nrows;
+        uint32_t wa[3], wb[3] = {0u, 0u, 0u};
+        np_load_quad(img + ((int64_t)(row0 + k) * W + xq * 4) * 3, dw, wa);
+        if (two) np_load_quad(img + ((int64_t)(row0 + k2) * W + xq2 * 4) * 3, dw, wb);
+        np_store_quad<MODE>(wa, out, n, row0 + k, xq * 4, P, ps, gh, gw, K, nc);
+        if (two) np_store_quad<MODE>(wb, out, n, row0 + k2, xq2 * 4, P, ps, gh, gw, K, nc);
+        k = k2 + adv_k;
+        xq = xq2 + adv_x;
         if (xq >= wq) { xq -= wq; ++k; }
     }
 }
@@ -1908,11 +1926,18 @@ int chb_normalize_patchify_bf16(const uint8_t* in, void* out, int B, int H, int 
     hipStream_t s = (hipStream_t)stream;
     bf16_t* o = (bf16_t*)out;
     if (B > 65535) return CHB_EUNSUPPORTED;
-    const dim3 g2((gh * patch + 15) / 16, B);
-    if (mode == CHB_NORM_TF) hipLaunchKernelGGL(normalize_patchify_kernel<1>, g2, dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
-    else if (mode == CHB_NORM_CAFFE) hipLaunchKernelGGL(normalize_patchify_kernel<0>, g2, dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kCaffe);
-    else if (mode == CHB_NORM_TORCH) hipLaunchKernelGGL(normalize_patchify_kernel<2>, g2, dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, kTorch);
+    static const int rows_env = getenv("CHB_NP_ROWS") ? atoi(getenv("CHB_NP_ROWS")) : 8;      // rows per wave (A/B: 4, 8, 16)
+#define CHB_NP_LAUNCH(MODE_, NC_)                                                                                                                  \
+    do {                                                                                                                                           \
+        if (rows_env == 4) hipLaunchKernelGGL((normalize_patchify_kernel<MODE_, 4>), dim3((gh * patch + 15) / 16, B), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, NC_);       \
+        else if (rows_env == 16) hipLaunchKernelGGL((normalize_patchify_kernel<MODE_, 16>), dim3((gh * patch + 63) / 64, B), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, NC_); \
+        else hipLaunchKernelGGL((normalize_patchify_kernel<MODE_, 8>), dim3((gh * patch + 31) / 32, B), dim3(256), 0, s, in, o, B, H, W, patch, gh, gw, NC_);                    \
+    } while (0)
+    if (mode == CHB_NORM_TF) CHB_NP_LAUNCH(1, kCaffe);
+    else if (mode == CHB_NORM_CAFFE) CHB_NP_LAUNCH(0, kCaffe);
+    else if (mode == CHB_NORM_TORCH) CHB_NP_LAUNCH(2, kTorch);
     else return CHB_EINVAL;
+#undef CHB_NP_LAUNCH
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }
