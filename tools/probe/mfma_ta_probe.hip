@@ -1,0 +1,372 @@
+// Hardware probe (not part of the library): how much of the MFMA pipe does a workgroup keep when LDS-DMA pieces and output stores
+// are issued between its MFMAs - with TWO waves per SIMD (8 waves, 128 accumulator registers each: the shape of
+// gemm_nt256sp_kernel) against ONE wave per SIMD (4 waves, 256 accumulator registers each)?  The traffic of one 256x256x64 K-step
+// is reproduced (64 one-KiB pieces: 32 from an activation-like panel that streams from HBM, 32 from a weight-like panel that
+// lives in L2) and, optionally, the 128 KiB of bf16 output of a tile either in one burst behind the tile's last K-step (today's
+// epilogue) or one store per few MFMA groups during the next tile (a carried tile).  No fragment reads unless READS: the question is
+// the address unit / store path, not LDS.  Results are meaningless numbers; only the rates count.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/probe/mfma_ta_probe tools/probe/mfma_ta_probe.hip && tools/probe/mfma_ta_probe
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <string.h>
+#include <math.h>
+#include <random>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int KSTEPS = 12;            // K = 768
+constexpr int LD = 768 * 2;           // bytes per operand row
+constexpr int M_ROWS = 100864;
+
+// PMODE (where a wave's pieces sit in its MFMA stream): 0 = one in front of each of the first groups of 8 MFMAs, every wave at the same
+// point; 1 = all of a wave's pieces in one burst in front of group `wave` (8 waves) / 4 `wave` (4 waves): one wave of the CU at a time, its
+// SIMD mate half a K-step away; 2 = as 0, but behind MFMA number `wave` of the group (2 `wave` for 4 waves): same count per group, the
+// eight waves 16-32 clocks apart
+// 3 (8 waves) = by age: the SIMD's older wave (0-3; the arbiter serves it first, so it runs ahead and then idles at the barrier) issues its
+// pieces in one burst BEHIND its last MFMA of the K-step, the younger (4-7) in one burst in FRONT of its first
+// MODE: 0 = no stores, 1 = burst of stores behind a tile's last K-step (+ barrier), 2 = stores spread over the next tile (every wave at
+// the same points of its instruction stream), 3 = spread AND staggered (no two waves of a SIMD, and at most two waves of the CU, store
+// at the same point)
+template <int WAVES, bool PIECES, int MODE, bool READS, int PMODE = 0, int DEPTH = 1>
+__global__ void __launch_bounds__(WAVES * 64) probe_kernel(const char* __restrict__ A, const char* __restrict__ B, char* __restrict__ C,
+                                                          const bf16x8_t* __restrict__ frag_init, int tiles, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];     // 2 x 64 KiB ring
+    constexpr int NACC = 256 / WAVES;              // float4 accumulators per wave (4 waves: 64 = 256 registers, 8 waves: 32 = 128)
+    constexpr int GROUPS = NACC / 4;               // groups of 8 MFMAs per K-step (every accumulator twice)
+    constexpr int PPW = 64 / WAVES;                // pieces per wave and K-step
+    constexpr int STORES = 128 / WAVES;            // 1 KiB stores per wave and tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+
+    float4_t acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[8], fb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fa[j] = frag_init[(j * 64 + lane) & 1023]; fb[j] = frag_init[((8 + j) * 64 + lane) & 1023]; }
+
+    const uint32_t lane_src = (uint32_t)((lane >> 3) * LD + (lane & 7) * 16);
+    uint4 carried = make_uint4(lane, wave, 3, 4);
+    int store_ix = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const int64_t row0 = ((int64_t)((t * gridDim.x + blockIdx.x) / 3) * 256) % (M_ROWS - 256);     // three workgroups share an A panel (N = 768)
+        const char* pa = A + row0 * LD;
+        const char* pb = B + (int64_t)((blockIdx.x % 3) * 256) * LD;
+        char* pc = C + ((int64_t)((t * gridDim.x + blockIdx.x) % 1000) * 256 * 256 * 2);
+        int stores_left = (MODE >= 2 && t > 0) ? STORES : 0;
+        for (int s = 0; s < KSTEPS; ++s) {
+            char* ring = lds + (s & 1) * 65536;
+            if (READS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    fa[j] = *reinterpret_cast<const bf16x8_t*>(ring + ((wave & 1) * 16 + j) * 1024 + lane * 16);
+                    fb[j] = *reinterpret_cast<const bf16x8_t*>(ring + 32768 + ((wave >> 1) * 8 + j) * 1024 + lane * 16);
+                }
+            }
+#pragma unroll
+            for (int grp = 0; grp < GROUPS; ++grp) {
+                auto piece = [&](int e) {
+                    // piece e: rows 8 e' .. 8 e' + 7 of the operand panel, 128 bytes of the K-step each
+                    const char* src = (e < 32 ? pa : pb) + (int64_t)((e & 31) * 8) * LD + s * 128 + lane_src;
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(ring + e * 1024), 16, 0, 0);
+                };
+                if (PIECES && PMODE == 0 && grp < PPW) piece(grp * WAVES + wave);
+                if (PIECES && (PMODE == 4 || PMODE == 5) && (wave < 4) == (PMODE == 4)) {      // 8 waves: one wave of each SIMD issues all pieces, two per group
+                    piece((2 * grp) * 4 + (wave & 3));
+                    piece((2 * grp + 1) * 4 + (wave & 3));
+                }
+                if (PIECES && PMODE == 3 && grp == 0 && wave >= 4) {
+#pragma unroll
+                    for (int q = 0; q < PPW; ++q) piece(q * WAVES + wave);
+                }
+                if (PIECES && PMODE == 1 && grp == wave * (GROUPS / WAVES)) {
+#pragma unroll
+                    for (int q = 0; q < PPW; ++q) piece(q * WAVES + wave);
+                }
+                // store slots: one per 4 groups of 8 MFMAs, over the first 8 K-steps of the next tile.  MODE 2: every wave in slot 0;
+                // MODE 3: wave w of SIMD w % 4 in slot w % 4, its SIMD mate (8 waves) two slots later
+                const int phase = MODE == 3 ? ((wave & 3) + 2 * (wave >> 2)) & 3 : 0;
+                if (MODE >= 2 && stores_left > 0 && (grp & 3) == phase) {
+                    *reinterpret_cast<uint4*>(pc + (int64_t)((store_ix & (STORES - 1)) * WAVES + wave) * 1024 + lane * 16) = carried;
+                    ++store_ix;
+                    --stores_left;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = (grp * 8 + j) % NACC;
+                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j], fb[(grp + j) & 7], acc[k], 0, 0, 0);
+                    if (PIECES && PMODE == 2 && grp < PPW && j == wave * (8 / WAVES)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(grp * WAVES + wave);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (PIECES && PMODE == 3 && grp == GROUPS - 1 && wave < 4) {
+                    auto piece = [&](int e) {
+                        const char* src = (e < 32 ? pa : pb) + (int64_t)((e & 31) * 8) * LD + s * 128 + lane_src;
+                        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(ring + e * 1024), 16, 0, 0);
+                    };
+#pragma unroll
+                    for (int q = 0; q < PPW; ++q) piece(q * WAVES + wave);
+                }
+            }
+            if (PIECES) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH * PPW * (PMODE >= 4 ? 2 : 1) + (MODE >= 2 ? 4 : 0)) : "memory");   // DEPTH K-steps of pieces stay in flight
+            __builtin_amdgcn_s_barrier();
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < STORES; ++e)
+                *reinterpret_cast<uint4*>(pc + (int64_t)(e * WAVES + wave) * 1024 + lane * 16) = carried;
+            __builtin_amdgcn_s_barrier();
+        }
+        carried.x += 1;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+    if (s == 12345.678f) sink[tid] = s;
+    if (tid == 0) {     // clocks this workgroup held: shader clocks / 100 MHz ticks
+        reinterpret_cast<unsigned long long*>(sink + 1024)[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - st0;
+        reinterpret_cast<unsigned long long*>(sink + 1024)[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    }
+}
+
+
+// ---- second probe: who pays for a store?  Waves of one workgroup take roles by wave id: MFMA waves issue `n_mfma` back-to-back MFMAs,
+// store waves issue `n_store` 1 KiB stores (or LDS-DMA pieces) back-to-back, the rest exit.  Every wave leaves its own elapsed shader
+// clocks; wave w sits on SIMD w % 4.
+__global__ void __launch_bounds__(512) roles_kernel(unsigned mfma_mask, unsigned store_mask, unsigned piece_mask, int n_mfma, int n_mem,
+                                                    const char* __restrict__ A, char* __restrict__ C, const bf16x8_t* __restrict__ frag_init,
+                                                    unsigned long long* __restrict__ cycles, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if ((mfma_mask >> wave) & 1) {
+        float4_t acc[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) acc[a] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        bf16x8_t fa[4], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fa[j] = frag_init[(j * 64 + lane) & 1023]; fb[j] = frag_init[((4 + j) * 64 + lane) & 1023]; }
+        const bool mixed = (mfma_mask >> (8 + wave)) & 1;        // this MFMA wave also issues one piece per 8 MFMAs (uniform)
+        const bool mixst = (mfma_mask >> (16 + wave)) & 1;       // ... or one 1 KiB store per 32 MFMAs
+        const char* pa = A + ((int64_t)((blockIdx.x * 8 + wave) & 31) << 22) + lane * 16;
+        char* pc = C + ((int64_t)(blockIdx.x * 8 + wave) << 22) + lane * 16;
+        const uint4 v = make_uint4(lane, wave, 3, 4);
+        for (int it = 0; it < n_mfma; it += 16) {
+            if (mixed) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(pa + (((it >> 3) & 255) << 10)), LDS_PTR(lds + wave * 8192 + ((it >> 3) & 7) * 1024), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (mixst && (it & 16)) {
+                *reinterpret_cast<uint4*>(pc + (((it >> 5) & 4095) << 10)) = v;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a & 3], fb[a >> 2], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (mixed) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(pa + ((((it >> 3) + 1) & 255) << 10)), LDS_PTR(lds + wave * 8192 + (((it >> 3) + 1) & 7) * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int a = 8; a < 16; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a & 3], fb[a >> 2], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+        if (s == 12345.678f) sink[tid] = s;
+    } else if ((store_mask >> wave) & 1) {
+        uint4 v = make_uint4(lane, wave, 3, 4);
+        char* pc = C + ((int64_t)(blockIdx.x * 8 + wave) << 22) + lane * 16;       // 4 MiB per wave, walked in 1 KiB steps
+        for (int it = 0; it < n_mem; ++it) *reinterpret_cast<uint4*>(pc + ((it & 4095) << 10)) = v;
+    } else if ((piece_mask >> wave) & 1) {
+        const char* pa = A + ((int64_t)((blockIdx.x * 8 + wave) & 31) << 22) + lane * 16;  // 32 x 4 MiB inside A; L2 / MALL resident after the first lap
+        for (int it = 0; it < n_mem; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pa + ((it & 255) << 10)), LDS_PTR(lds + wave * 8192 + (it & 7) * 1024), 16, 0, 0);
+            if ((it & 7) == 7) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) { cycles[blockIdx.x * 8 + wave] = t1 - t0; cycles[2048 + blockIdx.x * 8 + wave] = __builtin_amdgcn_s_memrealtime() - r0; }
+}
+
+static void roles(const char* name, unsigned mm, unsigned sm, unsigned pm, int n_mfma, int n_mem, const char* A, char* C, const bf16x8_t* fi,
+                  unsigned long long* cyc, float* sink) {
+    CHECK(hipFuncSetAttribute((const void*)roles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    static unsigned long long h[2 * 256 * 8];
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(roles_kernel, dim3(256), dim3(512), 131072, 0, mm, sm, pm, n_mfma, n_mem, A, C, fi, cyc, sink);
+        CHECK(hipDeviceSynchronize());
+    }
+    CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
+    printf("%-46s", name);
+    for (int w = 0; w < 8; ++w) {
+        double sum = 0;
+        for (int b = 0; b < 256; ++b) sum += (double)h[b * 8 + w];
+        printf(" w%d %8.0f", w, sum / 256.0);
+    }
+    printf("  shader clocks\n%-46s", "");
+    for (int w = 0; w < 8; ++w) {
+        double sum = 0;
+        for (int b = 0; b < 256; ++b) sum += (double)h[2048 + b * 8 + w];
+        printf(" w%d %8.1f", w, sum / 256.0 / 100.0);
+    }
+    printf("  us (100 MHz counter)\n");
+    fflush(stdout);
+}
+
+template <int WAVES, bool PIECES, int MODE, bool READS, int PMODE = 0, int DEPTH = 1>
+static void run(const char* name, const char* A, const char* B, char* C, const bf16x8_t* fi, float* sink, int tiles) {
+    auto k = probe_kernel<WAVES, PIECES, MODE, READS, PMODE, DEPTH>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k, dim3(256), dim3(WAVES * 64), 131072, 0, A, B, C, fi, tiles, sink);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double flop = 256.0 * tiles * KSTEPS * 256.0 * 256.0 * 64.0 * 2.0;
+    static unsigned long long hc[512];
+    CHECK(hipMemcpy(hc, sink + 1024, sizeof(hc), hipMemcpyDeviceToHost));
+    double clk = 0, ticks = 0;
+    for (int b = 0; b < 256; ++b) { clk += (double)hc[2 * b]; ticks += (double)hc[2 * b + 1]; }
+    const double ghz = clk / ticks * 0.1;                                             // last repetition
+    const double pipe = (double)tiles * KSTEPS * 2048.0 / (clk / 256.0);              // 2048 MFMA clocks per SIMD and K-step
+    printf("%-58s %8.3f ms  %7.1f TFLOP/s  (%.3f of 2.5 PF)  %.3f GHz  pipe %.3f\n", name, best, flop / best * 1e-9, flop / best * 1e-9 / 2500.0, ghz, pipe);
+    fflush(stdout);
+}
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+
+int main(int argc, char** argv) {
+    // operand data (power, hence clock, depends on it): "mantissa" = +-(2^-7 .. 2^-6) with random mantissas (default), "zeros",
+    // "gauss" = A ~ N(0, 1) (LayerNorm outputs), B ~ N(0, 0.02) (weights at initialisation)
+    const char* data = argc > 1 ? argv[1] : "mantissa";
+    const bool quick = argc > 2;
+    printf("operand data: %s\n", data);
+    const size_t a_bytes = (size_t)M_ROWS * LD, b_bytes = (size_t)768 * LD, c_bytes = (size_t)1000 * 256 * 256 * 2;
+    char *A, *B, *C;
+    bf16x8_t* fi;
+    float* sink;
+    CHECK(hipMalloc(&A, a_bytes));
+    CHECK(hipMalloc(&B, b_bytes));
+    CHECK(hipMalloc(&C, c_bytes));
+    CHECK(hipMalloc(&fi, 1024 * 16));
+    CHECK(hipMalloc(&sink, 4096 + 4096));
+    std::vector<uint16_t> h(a_bytes / 2);
+    uint32_t x = 12345;
+    std::vector<uint16_t> hb(b_bytes / 2), hf(8192);
+    if (!strcmp(data, "zeros")) {
+        for (auto& v : h) v = 0;
+        for (auto& v : hb) v = 0;
+        for (auto& v : hf) v = 0;
+    } else if (!strcmp(data, "gauss")) {
+        std::mt19937 gen(1);
+        std::normal_distribution<float> n01(0.f, 1.f);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = f2bf(n01(gen));
+        for (auto& v : hb) v = f2bf(0.02f * n01(gen));
+        for (int i = 0; i < 8192; ++i) hf[i] = ((i >> 9) & 8) ? f2bf(0.02f * n01(gen)) : f2bf(n01(gen));     // fragments 0-7: A-like, 8-15: B-like
+    } else {
+        for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((x >> 9) & 0x1ff) + ((x >> 31) << 15)); }   // +-(0.0078 .. 0.0156)
+        memcpy(hb.data(), h.data(), b_bytes);
+        memcpy(hf.data(), h.data() + 4096, 16384);
+    }
+    CHECK(hipMemcpy(A, h.data(), a_bytes, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(B, hb.data(), b_bytes, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(fi, hf.data(), 1024 * 16, hipMemcpyHostToDevice));
+    CHECK(hipMemset(C, 0, c_bytes));
+
+    if (!quick || argc > 3) {
+        unsigned long long* cyc;
+        CHECK(hipMalloc(&cyc, 2 * 256 * 8 * 8));
+        char* C2;
+        CHECK(hipMalloc(&C2, (size_t)256 * 8 << 22));      // 8 GiB of store targets
+        const int nm = 65536, ns = 16384;                  // 65536 MFMAs = 1.05 M pipe clocks; 16384 stores = 1.05 M clocks at 64 per store
+        roles("MFMA w0-3", 0x0f, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-7", 0xff, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("stores w4", 0, 0x10, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("stores w4-7", 0, 0xf0, 0, nm, ns / 4, A, C2, fi, cyc, sink);
+        roles("MFMA w0-3 + stores w4 (SIMD 0)", 0x0f, 0x10, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w1-3 + stores w4 (SIMD 0 alone)", 0x0e, 0x10, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-3 + stores w4-7", 0x0f, 0xf0, 0, nm, ns / 4, A, C2, fi, cyc, sink);
+        roles("MFMA w0-3,5-7 + stores w4", 0xef, 0x10, 0, nm / 2, ns / 2, A, C2, fi, cyc, sink);
+        roles("MFMA+pieces w0-3 (one per SIMD)", 0x0f0f, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-7, pieces in w4-7", 0xf0ff, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-7, pieces in w0-3", 0x0fff, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-7, pieces in all", 0xffff, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA+stores w0-3 (one per SIMD)", 0x0f000f, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-7, stores in w4-7", 0xf000ff, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-7, stores in all", 0xff00ff, 0, 0, nm, ns, A, C2, fi, cyc, sink);
+        roles("pieces w4", 0, 0, 0x10, nm, 4 * ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-3 + pieces w4 (SIMD 0)", 0x0f, 0, 0x10, nm, 4 * ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-3 + pieces w4-7", 0x0f, 0, 0xf0, nm, ns, A, C2, fi, cyc, sink);
+        roles("MFMA w0-3 + pieces w4,5 + stores w6", 0x0f, 0x40, 0x30, nm, ns, A, C2, fi, cyc, sink);
+    }
+    const int tiles = 1200;
+    // warm the clocks
+    run<8, false, 0, false>("(warm-up)", A, B, C, fi, sink, tiles);
+    run<8, false, 0, false>("8 waves, MFMA only", A, B, C, fi, sink, tiles);
+    run<4, false, 0, false>("4 waves, MFMA only", A, B, C, fi, sink, tiles);
+    run<8, true, 0, false>("8 waves, + 64 pieces / K-step", A, B, C, fi, sink, tiles);
+    run<4, true, 0, false>("4 waves, + 64 pieces / K-step", A, B, C, fi, sink, tiles);
+    run<8, true, 1, false>("8 waves, pieces + store burst per tile", A, B, C, fi, sink, tiles);
+    run<8, true, 0, true>("8 waves, pieces + fragment reads (compiler waits)", A, B, C, fi, sink, tiles);
+    run<8, true, 0, false, 4>("8 waves, all pieces in waves 0-3", A, B, C, fi, sink, tiles);
+    run<8, true, 0, false, 5>("8 waves, all pieces in waves 4-7", A, B, C, fi, sink, tiles);
+    run<8, true, 1, false, 4>("8 waves, all pieces in waves 0-3 + store burst", A, B, C, fi, sink, tiles);
+    run<8, true, 0, true, 4>("8 waves, all pieces in waves 0-3 + fragment reads", A, B, C, fi, sink, tiles);
+    if (quick) return 0;
+    run<8, true, 0, false, 0, 2>("8 waves, + 64 pieces / K-step, two steps in flight", A, B, C, fi, sink, tiles);
+    run<4, true, 0, false, 0, 2>("4 waves, + 64 pieces / K-step, two steps in flight", A, B, C, fi, sink, tiles);
+    run<8, true, 0, false, 0, 3>("8 waves, + 64 pieces / K-step, three steps in flight", A, B, C, fi, sink, tiles);
+    run<4, true, 0, false, 0, 3>("4 waves, + 64 pieces / K-step, three steps in flight", A, B, C, fi, sink, tiles);
+    run<8, true, 0, false, 1, 3>("8 waves, pieces in turn, three steps in flight", A, B, C, fi, sink, tiles);
+    run<8, true, 1, false, 0, 3>("8 waves, pieces (3 in flight) + store burst", A, B, C, fi, sink, tiles);
+    run<8, true, 3, false, 0, 3>("8 waves, pieces (3 in flight) + stores staggered", A, B, C, fi, sink, tiles);
+    run<4, true, 3, false, 0, 2>("4 waves, pieces (2 in flight) + stores staggered", A, B, C, fi, sink, tiles);
+    run<8, true, 0, false, 3, 2>("8 waves, pieces by age (old: behind, young: in front)", A, B, C, fi, sink, tiles);
+    run<8, true, 1, false, 3, 2>("8 waves, pieces by age + store burst", A, B, C, fi, sink, tiles);
+    run<8, true, 0, true, 3, 2>("8 waves, pieces by age + fragment reads (compiler waits)", A, B, C, fi, sink, tiles);
+    run<8, true, 0, false, 1>("8 waves, pieces in one burst per wave, waves in turn", A, B, C, fi, sink, tiles);
+    run<4, true, 0, false, 1>("4 waves, pieces in one burst per wave, waves in turn", A, B, C, fi, sink, tiles);
+    run<8, true, 0, false, 2>("8 waves, pieces behind MFMA `wave` of each group", A, B, C, fi, sink, tiles);
+    run<4, true, 0, false, 2>("4 waves, pieces behind MFMA 2 `wave` of each group", A, B, C, fi, sink, tiles);
+    run<8, true, 3, false, 1>("8 waves, pieces in turn + stores staggered", A, B, C, fi, sink, tiles);
+    run<8, true, 3, false, 2>("8 waves, pieces behind MFMA `wave` + stores staggered", A, B, C, fi, sink, tiles);
+    run<8, true, 1, false>("8 waves, pieces + store burst per tile", A, B, C, fi, sink, tiles);
+    run<4, true, 1, false>("4 waves, pieces + store burst per tile", A, B, C, fi, sink, tiles);
+    run<8, true, 2, false>("8 waves, pieces + stores spread over next tile", A, B, C, fi, sink, tiles);
+    run<4, true, 2, false>("4 waves, pieces + stores spread over next tile", A, B, C, fi, sink, tiles);
+    run<8, true, 3, false>("8 waves, pieces + stores spread and staggered", A, B, C, fi, sink, tiles);
+    run<4, true, 3, false>("4 waves, pieces + stores spread and staggered", A, B, C, fi, sink, tiles);
+    run<8, false, 3, false>("8 waves, staggered stores only", A, B, C, fi, sink, tiles);
+    run<4, false, 3, false>("4 waves, staggered stores only", A, B, C, fi, sink, tiles);
+    run<8, true, 0, true>("8 waves, pieces + fragment reads (compiler waits)", A, B, C, fi, sink, tiles);
+    run<4, true, 0, true>("4 waves, pieces + fragment reads (compiler waits)", A, B, C, fi, sink, tiles);
+    run<8, false, 1, false>("8 waves, store burst only", A, B, C, fi, sink, tiles);
+    run<4, false, 2, false>("4 waves, spread stores only", A, B, C, fi, sink, tiles);
+    return 0;
+}
