@@ -34,6 +34,7 @@ PROTOTYPES = {
     "chb_aug_sharpness": [P, P, c_int, c_int, c_int, c_int, c_float, P],
     "chb_aug_dispatch": [P, P, c_int, c_int, c_int, P, c_int, P, P],
     "chb_aug_fused": [P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P],
+    "chb_aug_fused_workspace_ints": [c_int, c_int, c_int, c_int],
     "chb_normalize_u8": [P, P, c_int64, c_int, c_int, P],
     "chb_normalize_f32": [P, P, c_int64, c_int, c_int, P],
     "chb_normalize_patchify_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, P],
@@ -115,6 +116,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = c_int
     lib.chb_version.restype = c_int
+    lib.chb_aug_fused_workspace_ints.restype = c_int64       # a size, not a status
     lib.chb_build_arch.restype = ctypes.c_char_p
     _lib = lib
     return lib
@@ -155,6 +157,11 @@ def require_gpu(*tensors):
 def set_option(name, value):
     """A/B switch of the library (see chb_set_option in include/chambers_hip.h); name without the CHB_ prefix."""
     call("chb_set_option", name.encode(), int(value))
+
+
+def aug_fused_workspace_ints(b, h, w, n_tables):
+    """int32 elements of chb_aug_fused's workspace (host arithmetic inside the library: it owns the slice count)."""
+    return int(load().chb_aug_fused_workspace_ints(int(b), int(h), int(w), int(n_tables)))
 
 
 def call(name, *args):

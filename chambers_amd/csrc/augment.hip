@@ -1352,6 +1352,64 @@ struct FusedEval<-1> {
     }
 };
 
+// ---- four pixels of level L at four arbitrary positions (below a warp): the positions travel down the chain, the values come back
+// up as one 12-byte quad, so every pointwise / table level is the vector code of the quad path instead of one byte-wise evaluation
+// per pixel (r03: a pixel-local op UNDER a warp cost 30 us more than the same op above it).  Sharpness under a warp keeps the
+// per-pixel evaluation (nine taps around each of four unrelated positions).
+template <int L>
+struct FusedGather {
+    static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, const int (&ys)[4], const int (&xs)[4], uint8_t (&b)[12]) {
+        const FusedOp& o = P.ops[L];
+        const int op = o.op;
+        if (op == CHB_AUG_SHARPNESS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t v = FusedEval<L>::at(P, C, ys[i], xs[i]);
+                b[3 * i + 0] = v & 0xff; b[3 * i + 1] = (v >> 8) & 0xff; b[3 * i + 2] = (v >> 16) & 0xff;
+            }
+            return;
+        }
+        if (op == CHB_AUG_AFFINE) {
+            int y2[4], x2[4];
+            bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ok[i] = affine_source(o, P.W, P.H, xs[i], ys[i], x2[i], y2[i]);
+            FusedGather<L - 1>::at(P, C, y2, x2, b);
+            const uint8_t fill = (uint8_t)(o.i0 & 0xff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = ok[i] ? b[3 * i + c] : fill;
+            return;
+        }
+        FusedGather<L - 1>::at(P, C, ys, xs, b);
+        if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
+            const uint8_t* lut = C.lut + L * 768;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
+        } else if (op == CHB_AUG_CUTOUT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool inside = cutout_inside(P, L, C.n, ys[i], xs[i]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+            }
+        } else {
+            quad_pointwise(op, b, o);
+        }
+    }
+};
+template <>
+struct FusedGather<-1> {
+    static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, const int (&ys)[4], const int (&xs)[4], uint8_t (&b)[12]) {
+#pragma unroll      // the four gathers in flight together
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t v = px_load(C.img, P.H, P.W, ys[i], xs[i]);
+            b[3 * i + 0] = v & 0xff; b[3 * i + 1] = (v >> 8) & 0xff; b[3 * i + 2] = (v >> 16) & 0xff;
+        }
+    }
+};
+
 // ---- four consecutive pixels (x0 % 4 == 0) of row y at level L; pixels at x >= W come back as anything and are never used ----
 // LOCAL: the launch holds no warp and no Sharpness (the host checked): a level reads only its own pixel, and the gather code is
 // compiled out (a third of the registers: twice the waves in flight)
@@ -1361,15 +1419,16 @@ struct FusedQuad {
         const FusedOp& o = P.ops[L];
         const int op = o.op;
         if (!LOCAL && op == CHB_AUG_AFFINE) {
-            const uint32_t fillw = ((uint32_t)(o.i0 & 0xff)) * 0x010101u;
-#pragma unroll      // the four gathers in flight together
-            for (int i = 0; i < 4; ++i) {
-                int sx, sy;
-                const bool ok = affine_source(o, P.W, P.H, x0 + i, y, sx, sy);
-                uint32_t v = FusedEval<L - 1>::at(P, C, sy, sx);
-                v = ok ? v : fillw;
-                b[3 * i + 0] = v & 0xff; b[3 * i + 1] = (v >> 8) & 0xff; b[3 * i + 2] = (v >> 16) & 0xff;
-            }
+            int ys[4], xs[4];
+            bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ok[i] = affine_source(o, P.W, P.H, x0 + i, y, xs[i], ys[i]);
+            FusedGather<L - 1>::at(P, C, ys, xs, b);
+            const uint8_t fill = (uint8_t)(o.i0 & 0xff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = ok[i] ? b[3 * i + c] : fill;
             return;
         }
         if (!LOCAL && op == CHB_AUG_SHARPNESS) {
@@ -1451,10 +1510,18 @@ __device__ __forceinline__ void fused_stage_luts(const FusedParams& P, int n, ui
     __syncthreads();
 }
 
-// histogram of level NLEV-1 (the input of the table op at level NLEV); grid = (row slices, B)
-template <int NLEV, bool LOCAL>
-__global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ ws, FusedParams P, int fast,
-                                                         int minmax) {
+// histogram of level NLEV-1 (the input of the table op at level NLEV); grid = (row slices, B).  Every workgroup leaves its OWN
+// partial table in `part` ([B][slices][768], plain stores: nothing to zero beforehand, no global atomics - r03: the zeroing launch in
+// front of this one cost a launch gap per table op); fused_lut_kernel adds the slices up.  The LDS bins are swizzled (a Posterize in
+// front leaves multiples of 8: one bank in eight).  NPOP "popular" values the host expects from the ops underneath - 0 and 255 behind
+// an op that clips (Brightness, Contrast, Color, SolarizeAdd), the fill value behind a warp - are counted by ballot into scalar
+// registers and skipped by the atomics: a same-address LDS atomic of 64 lanes is 64 serial updates (r02: X>Equalize 200-230 us
+// behind such an X, 106 us behind Invert).
+__device__ __forceinline__ int hist_slot(int bin) { return bin ^ ((bin >> 3) & 7) ^ (((bin >> 6) & 3) << 3); }
+
+template <int NLEV, bool LOCAL, int NPOP>
+__global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ part, FusedParams P, int fast,
+                                                         int minmax, int pop0, int pop1, int pop2) {
     __shared__ int32_t h[768];
     int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
@@ -1469,6 +1536,8 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
     const int adv_y = stride / wq, adv_x = stride - adv_y * wq;
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     int y = q / wq, xq = q - y * wq;
+    const int pops[3] = {pop0, pop1, pop2};
+    int cnt[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};        // [popular value][channel], wave-uniform (scalar registers)
     for (; q < nq; q += stride) {
         const int x0 = xq * 4;
         uint8_t b[12];
@@ -1482,27 +1551,46 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
                 if (x0 + i / 3 < P.W) { lo[i % 3] = min(lo[i % 3], (int)b[i]); hi[i % 3] = max(hi[i % 3], (int)b[i]); }
         } else {
 #pragma unroll
-            for (int i = 0; i < 12; ++i)
-                if (x0 + i / 3 < P.W) atomicAdd(&h[(i % 3) * 256 + b[i]], 1);
+            for (int i = 0; i < 12; ++i) {
+                const int v = (x0 + i / 3 < P.W) ? (int)b[i] : -1;
+                bool rare = v >= 0;
+#pragma unroll
+                for (int k = 0; k < NPOP; ++k) {
+                    cnt[k][i % 3] += (int)__builtin_popcountll(__ballot(v == pops[k]));
+                    rare = rare && (v != pops[k]);
+                }
+                if (rare) atomicAdd(&h[(i % 3) * 256 + hist_slot(v)], 1);
+            }
         }
     }
-    if (minmax) {      // AutoContrast needs the extremes only: slot 0 / 1 of each channel's table hold min / max
+    int32_t* mine = part + ((int64_t)n * gridDim.x + blockIdx.x) * 768;
+    if (minmax) {      // AutoContrast needs the extremes only: slots 0 / 1 of each channel's partial table hold min / max
+        __syncthreads();        // (the zeroing above is complete)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             for (int o = 32; o > 0; o >>= 1) {
                 lo[c] = min(lo[c], __shfl_xor(lo[c], o));
                 hi[c] = max(hi[c], __shfl_xor(hi[c], o));
             }
-            if ((threadIdx.x & 63) == 0) {
-                atomicMin(&ws[((int64_t)n * 3 + c) * 256], lo[c]);
-                atomicMax(&ws[((int64_t)n * 3 + c) * 256 + 1], hi[c]);
-            }
+            if ((threadIdx.x & 63) == 0) { h[(threadIdx.x >> 6) * 8 + 2 * c] = lo[c]; h[(threadIdx.x >> 6) * 8 + 2 * c + 1] = hi[c]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int c = threadIdx.x;
+            mine[c * 256] = min(min(h[2 * c], h[8 + 2 * c]), min(h[16 + 2 * c], h[24 + 2 * c]));
+            mine[c * 256 + 1] = max(max(h[2 * c + 1], h[8 + 2 * c + 1]), max(h[16 + 2 * c + 1], h[24 + 2 * c + 1]));
         }
         return;
     }
+    if (NPOP > 0 && (threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NPOP; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (cnt[k][c]) atomicAdd(&h[c * 256 + hist_slot(pops[k])], cnt[k][c]);
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < 768; i += blockDim.x)
-        if (h[i]) atomicAdd(&ws[(int64_t)n * 768 + i], h[i]);
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) mine[i] = h[(i & ~255) + hist_slot(i & 255)];
 }
 
 // final pass: grid = (row groups of 16, B); wave = 4 consecutive rows, lane = 4-pixel quad.
@@ -1556,13 +1644,26 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
     }
 }
 
-// table from the histogram of one (image, channel): the batch-shared op of level `lvl` (same code as lut_build_kernel)
-__global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ ws, int op) {
+// table from the histogram of one (image, channel): the batch-shared op of level `lvl` (same code as lut_build_kernel); the histogram
+// is the sum of the `slices` partial tables fused_hist_kernel left for the image (AutoContrast: min / max over their slots 0 / 1)
+__global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ tables, const int32_t* __restrict__ part, int slices, int op) {
     __shared__ int32_t s[256];
     __shared__ int32_t first_nz, last_nz;
-    int32_t* h = ws + (int64_t)blockIdx.x * 256;
+    __shared__ int32_t hsave[256];
+    const int n = blockIdx.x / 3, c = blockIdx.x - 3 * n;
     const int t = threadIdx.x;
-    const int32_t mine = h[t];
+    const int32_t* p0 = part + (int64_t)n * slices * 768 + c * 256 + t;
+    int32_t mine = 0;
+    if (op == CHB_AUG_AUTOCONTRAST) {
+        if (t < 2) {
+            mine = p0[0];
+            for (int k = 1; k < slices; ++k) mine = (t == 0) ? min(mine, p0[(int64_t)k * 768]) : max(mine, p0[(int64_t)k * 768]);
+        }
+    } else {
+        for (int k = 0; k < slices; ++k) mine += p0[(int64_t)k * 768];
+    }
+    int32_t* h = hsave;
+    h[t] = mine;
     s[t] = mine;
     if (t == 0) { first_nz = 255; last_nz = 0; }
     __syncthreads();
@@ -1597,7 +1698,7 @@ __global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ ws
             lut = lut < 0 ? 0 : (lut > 255 ? 255 : lut);
         }
     }
-    h[t] = lut;
+    tables[(int64_t)blockIdx.x * 256 + t] = lut;
 }
 
 const NormConst kCaffe = {{103.939f, 116.779f, 123.68f}, {1.f, 1.f, 1.f}};
@@ -1741,6 +1842,14 @@ int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const
 
 static bool fused_is_local(int op) { return op != CHB_AUG_AFFINE && op != CHB_AUG_SHARPNESS; }
 
+// workspace of ONE table op of chb_aug_fused: its [B][3][256] table, then the [B][slices][768] partial histograms it is made from
+static int64_t fused_table_ints(int B, int H, int W) { return (int64_t)B * 768 * (1 + slices_for((int64_t)H * W * 3, B)); }
+
+int64_t chb_aug_fused_workspace_ints(int B, int H, int W, int n_tables) {
+    if (B <= 0 || H <= 0 || W <= 0 || n_tables <= 0) return 0;
+    return (int64_t)n_tables * fused_table_ints(B, H, W);
+}
+
 // one segment of a chain: ops[0..n) evaluated per output pixel of `src`; returns the number of tables it used
 static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int n_ops, const FusedOp* ops, const int32_t* const* centers,
                          int32_t* ws, int patch, hipStream_t s) {
@@ -1754,20 +1863,39 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
         P.ops[l] = ops[l];
         P.centers[l] = centers[l];
         local = local && fused_is_local(ops[l].op);
-        if (ops[l].op == CHB_AUG_AUTOCONTRAST || ops[l].op == CHB_AUG_EQUALIZE) P.lut[l] = ws + (int64_t)(n_tables++) * B * 768;
+        if (ops[l].op == CHB_AUG_AUTOCONTRAST || ops[l].op == CHB_AUG_EQUALIZE) P.lut[l] = ws + (int64_t)(n_tables++) * fused_table_ints(B, H, W);
     }
-    // table ops, in chain order: histogram of the level below (evaluated through everything under it), then the table
+    // table ops, in chain order: partial histograms of the level below (evaluated through everything under it), then the table
+    const int slices = slices_for((int64_t)H * W * 3, B);
     for (int l = 0; l < n_ops; ++l) {
         if (!P.lut[l]) continue;
         int32_t* t = const_cast<int32_t*>(P.lut[l]);
-        const int nws = B * 768;
+        int32_t* part = t + (int64_t)B * 768;
         const int minmax = ops[l].op == CHB_AUG_AUTOCONTRAST ? 1 : 0;
-        hipLaunchKernelGGL(stats_init_kernel, dim3(chb_div_up(nws, 256)), dim3(256), 0, s, t, nws, minmax ? 0 : 1);
-        const dim3 grid(slices_for((int64_t)H * W * 3, B), B);
-#define CHB_FUSED_HIST(NL)                                                                                              \
-    do {                                                                                                                \
-        if (local) hipLaunchKernelGGL((fused_hist_kernel<NL, true>), grid, dim3(256), 0, s, src, t, P, fast, minmax);     \
-        else hipLaunchKernelGGL((fused_hist_kernel<NL, false>), grid, dim3(256), 0, s, src, t, P, fast, minmax);          \
+        const dim3 grid(slices, B);
+        // values the levels underneath make popular (see fused_hist_kernel): at most 0, 255 and one fill value
+        int pops[3] = {-2, -2, -2}, npop = 0;
+        bool clips = false;
+        int fillv = -1;
+        for (int k = 0; k < l; ++k) {
+            const int o = ops[k].op;
+            clips = clips || o == CHB_AUG_BRIGHTNESS || o == CHB_AUG_CONTRAST || o == CHB_AUG_COLOR || o == CHB_AUG_SOLARIZE_ADD;
+            if (o == CHB_AUG_AFFINE) fillv = ops[k].i0 & 0xff;
+            if (o == CHB_AUG_AUTOCONTRAST || o == CHB_AUG_EQUALIZE || o == CHB_AUG_INVERT || o == CHB_AUG_SOLARIZE || o == CHB_AUG_POSTERIZE) fillv = -1;   // remapped above the warp
+        }
+        if (clips) { pops[npop++] = 0; pops[npop++] = 255; }
+        if (fillv >= 0 && !(clips && (fillv == 0 || fillv == 255))) pops[npop++] = fillv;
+#define CHB_FUSED_HIST2(NL, NP)                                                                                                                    \
+    do {                                                                                                                                           \
+        if (local) hipLaunchKernelGGL((fused_hist_kernel<NL, true, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]);  \
+        else hipLaunchKernelGGL((fused_hist_kernel<NL, false, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]);       \
+    } while (0)
+#define CHB_FUSED_HIST(NL)                                   \
+    do {                                                     \
+        if (npop == 0 || minmax) CHB_FUSED_HIST2(NL, 0);     \
+        else if (npop == 1) CHB_FUSED_HIST2(NL, 1);          \
+        else if (npop == 2) CHB_FUSED_HIST2(NL, 2);          \
+        else CHB_FUSED_HIST2(NL, 3);                         \
     } while (0)
         switch (l) {
             case 0: CHB_FUSED_HIST(0); break;
@@ -1775,8 +1903,9 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
             case 2: CHB_FUSED_HIST(2); break;
             default: CHB_FUSED_HIST(3); break;
         }
+#undef CHB_FUSED_HIST2
 #undef CHB_FUSED_HIST
-        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, ops[l].op);
+        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, part, slices, ops[l].op);
     }
     int gh = 0, gw = 0;
     if (patch) { gh = H / patch; gw = W / patch; }
@@ -1852,7 +1981,7 @@ int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, 
             }
         } else {
             const int nt = fused_segment(src, dst, B, H, W, hi - lo, ops + lo, centers + lo, ws, last ? patch : 0, s);
-            if (ws) ws += (int64_t)nt * B * 768;
+            if (ws) ws += (int64_t)nt * fused_table_ints(B, H, W);
         }
         src = (const uint8_t*)dst;
         ++n_cut;

@@ -185,7 +185,7 @@ def aug_fused(x, plan, patch=None, out=None, scratch=True):
             keep.append(dev)
             cptr[l] = dev.data_ptr()
     nt = plan.n_tables
-    ws = torch.empty(nt * b * 768, dtype=torch.int32, device=x.device) if nt and b else None
+    ws = torch.empty(_lib.aug_fused_workspace_ints(b, h, w, nt), dtype=torch.int32, device=x.device) if nt and b else None
     if patch is None:
         out = torch.empty_like(x) if out is None else out
         if out.shape != x.shape or out.dtype != torch.uint8 or not out.is_contiguous():

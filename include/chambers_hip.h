@@ -311,8 +311,9 @@ int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const
  * of n_ops <= CHB_FUSED_MAX_OPS ops is evaluated per output pixel in ONE pass over the batch.  ops_host: n_ops HOST records
  *   struct { int32 op; int32 i0, i1, i2, i3; float f[6]; int32 pad; }    (48 bytes; op = CHB_AUG_*, fields as for chb_aug_dispatch;
  *   Contrast's i0 is the constant of the whole batch tensor, B*H*W/256 clipped), applied in order.
- * centers_dev[l]: device int32 [B,2] (cy, cx) for a CutOut at level l (else ignored / NULL).  workspace: int32 [n_tables*B*768]
- * when the chain holds AutoContrast / Equalize (each costs a histogram pass of the level below it + a table launch).
+ * centers_dev[l]: device int32 [B,2] (cy, cx) for a CutOut at level l (else ignored / NULL).  workspace: int32
+ * [chb_aug_fused_workspace_ints(B, H, W, n_tables)], uninitialised, when the chain holds AutoContrast / Equalize (each costs a
+ * histogram pass of the level below it, which leaves one partial table per workgroup, + a table launch that adds them up).
  * scratch: NULL, or 2*B*H*W*3 bytes.  NULL: the whole chain is evaluated per output pixel, the levels under a Sharpness at
  * each of its nine taps.  With scratch the chain is cut at its Sharpness ops, which then read a materialised uint8 image
  * through the stand-alone kernel (same bytes out, fewer gathers; the faster route); everything between two cuts is one launch.
@@ -322,6 +323,8 @@ int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const
 #define CHB_FUSED_MAX_OPS 4
 int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* ops_host,
                   const int32_t* const* centers_dev, int32_t* workspace, uint8_t* scratch, int patch, void* stream);
+/* int32 elements of chb_aug_fused's workspace for a chain with n_tables AutoContrast / Equalize ops (0 for none): host arithmetic only. */
+int64_t chb_aug_fused_workspace_ints(int B, int H, int W, int n_tables);
 
 /* Tuning / A-B switch `name` (ATTN_FWD_ALGO, ATTN_BWD_ALGO, AFFINE_ALGO, GEMM_ALGO, GEMM_WALK, TN_ATOMICS, TN_FAST,
  * GEMM_TILE_QUEUE; csrc/common.hpp) := value.  Defaults come from the environment variables CHB_<name>, read once per

@@ -4,7 +4,8 @@ ways on a [B,224,224,3] uint8 batch, over all 16 x 16 ordered op pairs (the sche
   op-by-op     one launch per op, then chb_normalize_patchify_bf16
   elementwise  per-image decisions: chb_aug_dispatch per slot, then chb_normalize_patchify_bf16
 Algorithmic bytes of the stage = uint8 batch read once + bf16 patch rows written once = 3 * B*H*W*3, whatever the chain.
-Every configuration is replayed from a HIP graph (the kernels are shorter than a Python layer call)."""
+Every configuration is replayed from a HIP graph (the kernels are shorter than a Python layer call).
+  CHB_STAGE_FUSED_ONLY=1: time the fused path alone and print its table (A/B builds through CHB_AB_LIB: tools/ab_build.sh)."""
 import itertools
 import json
 import os
@@ -14,6 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
+if os.environ.get("CHB_AB_LIB"):
+    from chambers_amd import _build
+    _build.LIB_PATH = os.path.abspath(os.environ["CHB_AB_LIB"])
+FUSED_ONLY = os.environ.get("CHB_STAGE_FUSED_ONLY", "0") == "1"
 from chambers_amd import augmentations as aug
 from chambers_amd import kernels as K
 
@@ -56,10 +61,22 @@ for a, b in itertools.product(range(16), range(16)):
     dec = decisions(a, b)
     plan = layer.plan(x.shape, dec)
     t_fused = timed(lambda: K.aug_fused(x, plan, patch=16, out=patches))
+    if FUSED_ONLY:
+        rows["%s>%s" % (names[a], names[b])] = (t_fused, t_fused)
+        continue
     layer._transform.fused = False
     t_ops = timed(lambda: K.normalize_patchify(layer(x, training=True, decisions=dec), 16, "tf", out=patches))
     layer._transform.fused = True
     rows["%s>%s" % (names[a], names[b])] = (t_fused, t_ops)
+
+if FUSED_ONLY:
+    fused = np.array([v[0] for v in rows.values()])
+    print("fused, mean of 256 pairs %.1f us; min %.1f (%s) max %.1f (%s)" % (fused.mean(), fused.min(), list(rows)[int(fused.argmin())], fused.max(),
+                                                                                 list(rows)[int(fused.argmax())]))
+    print("%-13s" % "" + "".join("%7s" % n[:6] for n in names))
+    for a in names:
+        print("%-13s" % a + "".join("%7.0f" % rows[a + ">" + b][0] for b in names))
+    sys.exit(0)
 
 # elementwise: every image its own pair (uniform draws), resident op records
 items = np.zeros((2, B), dtype=K.AUG_ITEM_DTYPE)
