@@ -10,6 +10,8 @@
 // Reference semantics: chambers/augmentations/image_augmentations.py (lines cited per
 // kernel); upstream TF / tensorflow-addons behaviour as restated in oracle/augment_ref.py.
 #include "common.hpp"
+#include <mutex>
+#include <vector>
 #include "../../include/chambers_hip.h"
 #include <string.h>
 
@@ -1411,14 +1413,23 @@ struct FusedGather<-1> {
 };
 
 // ---- four consecutive pixels (x0 % 4 == 0) of row y at level L; pixels at x >= W come back as anything and are never used ----
-// LOCAL: the launch holds no warp and no Sharpness (the host checked): a level reads only its own pixel, and the gather code is
-// compiled out (a third of the registers: twice the waves in flight)
-template <int L, bool LOCAL>
+// MODE (decided by the host per launch, so that a launch carries only the code it needs - a third of the registers and twice the
+// waves in flight for the lean ones):
+//   FUSED_LOCAL   no warp, no Sharpness: a level reads only its own pixel;
+//   FUSED_ROWS    no Sharpness, and every warp is ROW-CONTIGUOUS (TranslateX / TranslateY / ShearX; affine_row_contiguous checked every
+//                 pixel of this H x W): the source of (x, y) is (x + d(y), r(y)), so a quad reads ONE run of four pixels - the
+//                 levels underneath are evaluated as a quad at the shifted start (any x0, also outside the row: masked on the way
+//                 up), one affine evaluation per quad instead of four and no per-pixel gathers;
+//   FUSED_GENERAL everything else (per-pixel gathers below a warp, windows below a Sharpness).
+constexpr int FUSED_GENERAL = 0, FUSED_LOCAL = 1, FUSED_ROWS = 2;
+struct __attribute__((aligned(4))) u32x4_a4 { uint32_t w[4]; };
+
+template <int L, int MODE>
 struct FusedQuad {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
         const FusedOp& o = P.ops[L];
         const int op = o.op;
-        if (!LOCAL && op == CHB_AUG_AFFINE) {
+        if (MODE == FUSED_GENERAL && op == CHB_AUG_AFFINE) {
             int ys[4], xs[4];
             bool ok[4];
 #pragma unroll
@@ -1431,7 +1442,7 @@ struct FusedQuad {
                 for (int c = 0; c < 3; ++c) b[3 * i + c] = ok[i] ? b[3 * i + c] : fill;
             return;
         }
-        if (!LOCAL && op == CHB_AUG_SHARPNESS) {
+        if (MODE == FUSED_GENERAL && op == CHB_AUG_SHARPNESS) {
             // window rows y-1..y+1, columns x0-1..x0+4: three quads + the two edge columns, 18 evaluations for 4 outputs; the
             // taps are summed in row-major order, so the rows can be folded into the 12 sums as they arrive
             const bool yin = (y >= 1) && (y < P.H - 1);
@@ -1444,7 +1455,7 @@ struct FusedQuad {
             for (int r = yin ? 0 : 1; r < (yin ? 3 : 2); ++r) {
                 uint8_t w[18];
                 uint8_t q[12];
-                FusedQuad<L - 1, LOCAL>::at(P, C, y + r - 1, x0, q);
+                FusedQuad<L - 1, MODE>::at(P, C, y + r - 1, x0, q);
                 const uint32_t lft = (yin && x0 >= 1) ? FusedEval<L - 1>::at(P, C, y + r - 1, x0 - 1) : 0u;
                 const uint32_t rgt = (yin && x0 + 4 < P.W) ? FusedEval<L - 1>::at(P, C, y + r - 1, x0 + 4) : 0u;
                 w[0] = lft & 0xff; w[1] = (lft >> 8) & 0xff; w[2] = (lft >> 16) & 0xff;
@@ -1477,7 +1488,7 @@ struct FusedQuad {
             }
             return;
         }
-        FusedQuad<L - 1, LOCAL>::at(P, C, y, x0, b);
+        FusedQuad<L - 1, MODE>::at(P, C, y, x0, b);
         if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
             const uint8_t* lut = C.lut + L * 768;
 #pragma unroll
@@ -1494,14 +1505,105 @@ struct FusedQuad {
         }
     }
 };
-template <bool LOCAL>
-struct FusedQuad<-1, LOCAL> {
+template <int MODE>
+struct FusedQuad<-1, MODE> {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
         const uint8_t* row = C.img + (int64_t)y * P.W * 3;
         if (C.fast) load_quad<true>(row, x0, P.W, b);
         else load_quad<false>(row, x0, P.W, b);
     }
 };
+
+// ---- FUSED_ROWS: four pixels of ONE row y of level L at columns xs[0..3] (a run x0 .. x0+3 at the top; under a warp whatever its
+// row map makes of them - for a pure shift again a run).  Level -1 loads a run with one 16-byte access, anything else per pixel.
+template <int L>
+struct FusedRow {
+    static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, const int (&xs)[4], uint8_t (&b)[12]) {
+        const FusedOp& o = P.ops[L];
+        const int op = o.op;
+        if (op == CHB_AUG_AFFINE) {             // f[3] == 0 (host): the source row does not depend on x
+            const float fy = (float)y;
+            const float ry = roundf((o.f[3] * 0.0f + o.f[4] * fy) + o.f[5]);
+            const bool rowok = (ry >= 0.0f) && (ry < (float)P.H);
+            const uint8_t fill = (uint8_t)(o.i0 & 0xff);
+            int x2[4];
+            bool ok[4];
+            if (o.pad == 1) {                   // a pure shift on this H x W (affine_row_contiguous): no per-pixel evaluation at all
+                const int d = (int)roundf((o.f[0] * 0.0f + o.f[1] * fy) + o.f[2]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { x2[i] = xs[i] + d; ok[i] = rowok && (x2[i] >= 0) && (x2[i] < P.W); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float rx = roundf((o.f[0] * (float)xs[i] + o.f[1] * fy) + o.f[2]);
+                    ok[i] = rowok && (rx >= 0.0f) && (rx < (float)P.W);
+                    x2[i] = ok[i] ? (int)rx : 0;
+                }
+            }
+            if (!(ok[0] || ok[1] || ok[2] || ok[3])) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) b[i] = fill;
+                return;
+            }
+            FusedRow<L - 1>::at(P, C, (int)ry, x2, b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = ok[i] ? b[3 * i + c] : fill;
+            return;
+        }
+        FusedRow<L - 1>::at(P, C, y, xs, b);
+        if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
+            const uint8_t* lut = C.lut + L * 768;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
+        } else if (op == CHB_AUG_CUTOUT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool inside = cutout_inside(P, L, C.n, y, xs[i]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+            }
+        } else {
+            quad_pointwise(op, b, o);
+        }
+    }
+};
+template <>
+struct FusedRow<-1> {
+    static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, const int (&xs)[4], uint8_t (&b)[12]) {
+        // A run (also one that leaves the row: those pixels are masked above): one 16-byte load from the dword below + byte
+        // alignment.  Bytes in front of / behind this image belong to its neighbours in the batch; only the first and the last
+        // image have none there.  Everything else: per-pixel loads at columns clamped into the row.
+        const int off = (y * P.W + xs[0]) * 3, lo = off & ~3, end = P.H * P.W * 3;
+        const bool run = (xs[1] == xs[0] + 1) && (xs[2] == xs[0] + 2) && (xs[3] == xs[0] + 3);
+        if (run && (lo >= 0 || C.n > 0) && (lo + 16 <= end || C.n + 1 < P.B)) {
+            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(C.img + lo);
+            const uint32_t sh = (uint32_t)(off & 3);
+            const uint32_t w0 = __builtin_amdgcn_alignbyte(v.w[1], v.w[0], sh), w1 = __builtin_amdgcn_alignbyte(v.w[2], v.w[1], sh),
+                           w2 = __builtin_amdgcn_alignbyte(v.w[3], v.w[2], sh);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t v = px_load(C.img, P.H, P.W, y, min(max(xs[i], 0), P.W - 1));
+                b[3 * i + 0] = v & 0xff; b[3 * i + 1] = (v >> 8) & 0xff; b[3 * i + 2] = (v >> 16) & 0xff;
+            }
+        }
+    }
+};
+
+// the quad (y, x0 .. x0+3) of the launch's top level
+template <int L, int MODE>
+__device__ __forceinline__ void fused_top_quad(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
+    if (MODE == FUSED_ROWS) {
+        const int xs[4] = {x0, x0 + 1, x0 + 2, x0 + 3};
+        FusedRow<L>::at(P, C, y, xs, b);
+    } else {
+        FusedQuad<L, MODE>::at(P, C, y, x0, b);
+    }
+}
 
 __device__ __forceinline__ void fused_stage_luts(const FusedParams& P, int n, uint8_t* lutS) {
     for (int l = 0; l < P.n; ++l)       // uniform
@@ -1519,7 +1621,7 @@ __device__ __forceinline__ void fused_stage_luts(const FusedParams& P, int n, ui
 // behind such an X, 106 us behind Invert).
 __device__ __forceinline__ int hist_slot(int bin) { return bin ^ ((bin >> 3) & 7) ^ (((bin >> 6) & 3) << 3); }
 
-template <int NLEV, bool LOCAL, int NPOP>
+template <int NLEV, int MODE, int NPOP>
 __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ part, FusedParams P, int fast,
                                                          int minmax, int pop0, int pop1, int pop2) {
     __shared__ int32_t h[768];
@@ -1541,7 +1643,7 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
     for (; q < nq; q += stride) {
         const int x0 = xq * 4;
         uint8_t b[12];
-        FusedQuad<NLEV - 1, LOCAL>::at(P, C, y, x0, b);
+        fused_top_quad<NLEV - 1, MODE>(P, C, y, x0, b);
         y += adv_y;
         xq += adv_x;
         if (xq >= wq) { xq -= wq; ++y; }
@@ -1595,7 +1697,7 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
 
 // final pass: grid = (row groups of 16, B); wave = 4 consecutive rows, lane = 4-pixel quad.
 // PATCH: "tf" normalisation + bf16 patch rows (patch % 4 == 0: a quad never straddles patches), else uint8 NHWC
-template <int NLEV, bool PATCH, bool LOCAL>
+template <int NLEV, bool PATCH, int MODE>
 __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw,
                                                           int fast) {
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
@@ -1620,7 +1722,7 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
     for (; k < nrows; ) {
         const int y = row0 + k, x0 = xq * 4;
         uint8_t b[12];
-        FusedQuad<NLEV - 1, LOCAL>::at(P, C, y, x0, b);
+        fused_top_quad<NLEV - 1, MODE>(P, C, y, x0, b);
         if (PATCH) {
             float f[12];
 #pragma unroll
@@ -1842,6 +1944,36 @@ int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const
 
 static bool fused_is_local(int op) { return op != CHB_AUG_AFFINE && op != CHB_AUG_SHARPNESS; }
 
+// Is the nearest-neighbour warp `o` on an H x W image a pure per-row shift - source of (x, y) = (x + d(y), r(y)) for EVERY x of the row,
+// d(y) the rounded source column of x = 0?  (Not so where a source column is an exact tie: half-away rounding flips with the sign and
+// with the binade of the sum - ShearX by -0.27 on rows 50 and 150 of a 224-row image.)  Decided by evaluating the device's own expression (same float order, this file is built without contraction) at
+// every pixel, once per (coefficients, H, W): RandAugment draws a sign, not a magnitude, so a run sees two records per op.
+static bool affine_row_contiguous(const FusedOp& o, int H, int W) {
+    if (o.f[0] != 1.0f || o.f[3] != 0.0f) return false;
+    struct Entry { float f[6]; int H, W; bool yes; };
+    static std::mutex mu;
+    static std::vector<Entry> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry& e : seen)
+        if (e.H == H && e.W == W && !memcmp(e.f, o.f, sizeof(e.f))) return e.yes;
+    bool yes = true;
+    for (int y = 0; y < H && yes; ++y) {
+        const float fy = (float)y;
+        const float d = roundf((o.f[0] * 0.0f + o.f[1] * fy) + o.f[2]);
+        if (!(fabsf(d) < 1.0e6f)) { yes = false; break; }
+        for (int x = 0; x < W; ++x) {
+            const float fx = (float)x;
+            if (roundf((o.f[0] * fx + o.f[1] * fy) + o.f[2]) != fx + d) { yes = false; break; }
+        }
+    }
+    if (seen.size() >= 256) seen.clear();
+    Entry e;
+    memcpy(e.f, o.f, sizeof(e.f));
+    e.H = H; e.W = W; e.yes = yes;
+    seen.push_back(e);
+    return yes;
+}
+
 // workspace of ONE table op of chb_aug_fused: its [B][3][256] table, then the [B][slices][768] partial histograms it is made from
 static int64_t fused_table_ints(int B, int H, int W) { return (int64_t)B * 768 * (1 + slices_for((int64_t)H * W * 3, B)); }
 
@@ -1858,11 +1990,13 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
     P.n = n_ops; P.B = B; P.H = H; P.W = W;
     const int fast = ((W & 3) == 0 && !((uintptr_t)src & 3) && (patch || !((uintptr_t)dst & 3))) ? 1 : 0;
     int n_tables = 0;
-    bool local = true;
+    bool local = true, rows = true;      // rows: no Sharpness and every warp row-contiguous (FUSED_ROWS)
     for (int l = 0; l < n_ops; ++l) {
         P.ops[l] = ops[l];
         P.centers[l] = centers[l];
         local = local && fused_is_local(ops[l].op);
+        rows = rows && ops[l].op != CHB_AUG_SHARPNESS && (ops[l].op != CHB_AUG_AFFINE || ops[l].f[3] == 0.0f);
+        P.ops[l].pad = (ops[l].op == CHB_AUG_AFFINE && ops[l].f[3] == 0.0f && affine_row_contiguous(ops[l], H, W)) ? 1 : 0;
         if (ops[l].op == CHB_AUG_AUTOCONTRAST || ops[l].op == CHB_AUG_EQUALIZE) P.lut[l] = ws + (int64_t)(n_tables++) * fused_table_ints(B, H, W);
     }
     // table ops, in chain order: partial histograms of the level below (evaluated through everything under it), then the table
@@ -1885,10 +2019,11 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
         }
         if (clips) { pops[npop++] = 0; pops[npop++] = 255; }
         if (fillv >= 0 && !(clips && (fillv == 0 || fillv == 255))) pops[npop++] = fillv;
-#define CHB_FUSED_HIST2(NL, NP)                                                                                                                    \
-    do {                                                                                                                                           \
-        if (local) hipLaunchKernelGGL((fused_hist_kernel<NL, true, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]);  \
-        else hipLaunchKernelGGL((fused_hist_kernel<NL, false, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]);       \
+#define CHB_FUSED_HIST2(NL, NP)                                                                                                                            \
+    do {                                                                                                                                                   \
+        if (local) hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_LOCAL, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]);   \
+        else if (rows) hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_ROWS, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]); \
+        else hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_GENERAL, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]);       \
     } while (0)
 #define CHB_FUSED_HIST(NL)                                   \
     do {                                                     \
@@ -1910,10 +2045,11 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
     int gh = 0, gw = 0;
     if (patch) { gh = H / patch; gw = W / patch; }
     const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);
-#define CHB_FUSED_FINAL2(NL, PT)                                                                                                   \
-    do {                                                                                                                           \
-        if (local) hipLaunchKernelGGL((fused_final_kernel<NL, PT, true>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);  \
-        else hipLaunchKernelGGL((fused_final_kernel<NL, PT, false>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);       \
+#define CHB_FUSED_FINAL2(NL, PT)                                                                                                            \
+    do {                                                                                                                                    \
+        if (local) hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_LOCAL>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);     \
+        else if (rows) hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_ROWS>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);  \
+        else hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_GENERAL>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);         \
     } while (0)
 #define CHB_FUSED_FINAL(NL)                \
     do {                                   \
