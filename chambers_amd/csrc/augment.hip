@@ -11,6 +11,7 @@
 // kernel); upstream TF / tensorflow-addons behaviour as restated in oracle/augment_ref.py.
 #include "common.hpp"
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include "../../include/chambers_hip.h"
 #include <string.h>
@@ -1615,15 +1616,15 @@ __device__ __forceinline__ void fused_stage_luts(const FusedParams& P, int n, ui
 // histogram of level NLEV-1 (the input of the table op at level NLEV); grid = (row slices, B).  Every workgroup leaves its OWN
 // partial table in `part` ([B][slices][768], plain stores: nothing to zero beforehand, no global atomics - r03: the zeroing launch in
 // front of this one cost a launch gap per table op); fused_lut_kernel adds the slices up.  The LDS bins are swizzled (a Posterize in
-// front leaves multiples of 8: one bank in eight).  NPOP "popular" values the host expects from the ops underneath - 0 and 255 behind
+// front leaves multiples of 8: one bank in eight).  `npop` "popular" values the host expects from the ops underneath - 0 and 255 behind
 // an op that clips (Brightness, Contrast, Color, SolarizeAdd), the fill value behind a warp - are counted by ballot into scalar
 // registers and skipped by the atomics: a same-address LDS atomic of 64 lanes is 64 serial updates (r02: X>Equalize 200-230 us
 // behind such an X, 106 us behind Invert).
 __device__ __forceinline__ int hist_slot(int bin) { return bin ^ ((bin >> 3) & 7) ^ (((bin >> 6) & 3) << 3); }
 
-template <int NLEV, int MODE, int NPOP>
+template <int NLEV, int MODE>
 __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ part, FusedParams P, int fast,
-                                                         int minmax, int pop0, int pop1, int pop2) {
+                                                         int minmax, int npop, int pop0, int pop1, int pop2) {
     __shared__ int32_t h[768];
     int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
@@ -1657,10 +1658,11 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
                 const int v = (x0 + i / 3 < P.W) ? (int)b[i] : -1;
                 bool rare = v >= 0;
 #pragma unroll
-                for (int k = 0; k < NPOP; ++k) {
-                    cnt[k][i % 3] += (int)__builtin_popcountll(__ballot(v == pops[k]));
-                    rare = rare && (v != pops[k]);
-                }
+                for (int k = 0; k < 3; ++k)
+                    if (k < npop) {         // uniform
+                        cnt[k][i % 3] += (int)__builtin_popcountll(__ballot(v == pops[k]));
+                        rare = rare && (v != pops[k]);
+                    }
                 if (rare) atomicAdd(&h[(i % 3) * 256 + hist_slot(v)], 1);
             }
         }
@@ -1684,12 +1686,12 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
         }
         return;
     }
-    if (NPOP > 0 && (threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < NPOP; ++k)
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                if (cnt[k][c]) atomicAdd(&h[c * 256 + hist_slot(pops[k])], cnt[k][c]);
+                if (k < npop && cnt[k][c]) atomicAdd(&h[c * 256 + hist_slot(pops[k])], cnt[k][c]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 768; i += blockDim.x) mine[i] = h[(i & ~255) + hist_slot(i & 255)];
@@ -1743,6 +1745,141 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
         k += adv_k;
         xq += adv_x;
         if (xq >= wq) { xq -= wq; ++k; }
+    }
+}
+
+// ---- a Sharpness with the chain around it in ONE launch (r03; before: the levels below into a uint8 scratch image, the stand-alone
+// Sharpness into another, then normalise + patchify - three launches and two round trips).  A wave walks down 8 output rows, a lane
+// owns the same quad in all of them; each input row is a quad of level S-1, evaluated once where it is needed (BMODE: the launch
+// mode of the levels below; S = 0: plain loads), the halo pixels come from the neighbouring lanes.  Every input byte is converted and
+// multiplied by 1/13 once, the per-output sum keeps the reference's row-major order (as in sharpness_rows_kernel).  The levels above
+// the Sharpness must be pixel-local (host): they are applied to the finished quad, then the quad leaves as uint8 or as
+// "tf"-normalised bf16 patch rows.  grid = (groups of 4 x 8 rows, B).
+template <int S, int BMODE>
+__device__ __forceinline__ void fused_below_quad(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&q)[12]) {
+    if (S == 0) FusedQuad<-1, FUSED_LOCAL>::at(P, C, y, x0, q);
+    else fused_top_quad<(S > 0 ? S - 1 : 0), BMODE>(P, C, y, x0, q);
+}
+
+template <int S, bool PATCH, int BMODE>
+__global__ void __launch_bounds__(256) fused_sharp_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw,
+                                                          int fast) {
+    constexpr int R = 8;             // output rows per wave: R + 2 rows of level S-1 are evaluated for them (1.25 per output row)
+    __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
+    const int n = blockIdx.y;
+    fused_stage_luts(P, n, lutS);
+    const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int H = P.H, W = P.W;
+    const int wq = PATCH ? (gw * patch) >> 2 : (W + 3) >> 2;       // quads written per row
+    const int wq_in = (W + 3) >> 2;                                 // quads that exist in a row (halo source)
+    const int hh = PATCH ? gh * patch : H;
+    const int y0 = (blockIdx.x * 4 + wave) * R;
+    if (y0 >= hh) return;
+    const int y1 = min(y0 + R, hh);                                 // output rows y0 .. y1-1
+    const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+    const FusedOp& so = P.ops[S];
+    const float factor = so.f[0];
+    const bool clip = !(factor > 0.0f && factor < 1.0f);
+    const int K = patch * patch * 3;
+    const int ps = (PATCH && (patch & (patch - 1)) == 0) ? (31 - __builtin_clz(patch)) : -1;     // uniform
+    // a window of 64 lanes = 62 output quads + one halo quad on either side (evaluated, not written): every halo pixel is a
+    // neighbouring lane's.  The wave walks DOWN its rows with a three-row window of products: one evaluation of the chain below per
+    // input row, one copy of its code in the kernel.
+    for (int xb = 0; xb < wq; xb += 62) {
+        const int xq = xb - 1 + lane;
+        const bool live = (xq >= 0) && (xq < wq_in);
+        const bool writes = (lane >= 1) && (lane <= 62) && (xq < wq);
+        const int x0 = xq * 4;
+        float pa[18], pb[18];     // (float)byte * k1 for [left px | own 4 px | right px] of input rows y-1, y
+        uint8_t ownb[12];         // level S-1 at row y
+#pragma unroll
+        for (int i = 0; i < 18; ++i) { pa[i] = 0.0f; pb[i] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) ownb[i] = 0;
+#pragma unroll 1
+        for (int yy = y0 - 1; yy <= y1; ++yy) {            // input row yy completes the window of output row yy - 1
+            const bool rin = (yy >= 0) && (yy < H);        // rows outside the image are never used: border rows keep the original
+            uint8_t q[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) q[i] = 0;
+            if (rin && live) fused_below_quad<S, BMODE>(P, C, yy, x0, q);
+            const uint32_t lft = __shfl_up((uint32_t)q[9] | ((uint32_t)q[10] << 8) | ((uint32_t)q[11] << 16), 1, 64);
+            const uint32_t rgt = __shfl_down((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16), 1, 64);
+            float pc[18];
+            pc[0] = (float)(lft & 0xff) * k1;
+            pc[1] = (float)((lft >> 8) & 0xff) * k1;
+            pc[2] = (float)((lft >> 16) & 0xff) * k1;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) pc[3 + i] = (float)q[i] * k1;
+            pc[15] = (float)(rgt & 0xff) * k1;
+            pc[16] = (float)((rgt >> 8) & 0xff) * k1;
+            pc[17] = (float)((rgt >> 16) & 0xff) * k1;
+            const int y = yy - 1;
+            if (y >= y0 && writes) {                       // (y < y1 by the loop bound)
+                const bool yin = (y >= 1) && (y < H - 1);
+                uint8_t b[12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int x = x0 + i;
+                    const bool interior = yin && (x >= 1) && (x < W - 1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint8_t orig = ownb[3 * i + c];
+                        // window column (i + kx) of a row is pixel x - 1 + kx; pa, pb, pc are rows y-1, y, y+1
+                        float acc = pa[3 * i + c];
+                        acc = acc + pa[3 * (i + 1) + c];
+                        acc = acc + pa[3 * (i + 2) + c];
+                        acc = acc + pb[3 * i + c];
+                        acc = acc + (float)orig * k5;
+                        acc = acc + pb[3 * (i + 2) + c];
+                        acc = acc + pc[3 * i + c];
+                        acc = acc + pc[3 * (i + 1) + c];
+                        acc = acc + pc[3 * (i + 2) + c];
+                        const uint8_t deg = interior ? trunc_u8(acc) : orig;
+                        b[3 * i + c] = (factor == 0.0f) ? deg : blend_rt(deg, orig, factor, clip);
+                    }
+                }
+                for (int l = S + 1; l < P.n; ++l) {          // the pixel-local levels above (uniform)
+                    const FusedOp& o = P.ops[l];
+                    if (o.op == CHB_AUG_AUTOCONTRAST || o.op == CHB_AUG_EQUALIZE) {
+                        const uint8_t* lut = C.lut + l * 768;
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
+                    } else if (o.op == CHB_AUG_CUTOUT) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool inside = cutout_inside(P, l, C.n, y, x0 + i);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+                        }
+                    } else {
+                        quad_pointwise(o.op, b, o);
+                    }
+                }
+                if (PATCH) {
+                    float f[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) f[i] = norm1<1>(b[i], i % 3, NormConst{});
+                    int py, px, ry, rx;
+                    if (ps >= 0) { py = y >> ps; px = x0 >> ps; ry = y & (patch - 1); rx = x0 & (patch - 1); }
+                    else { py = y / patch; px = x0 / patch; ry = y - py * patch; rx = x0 - px * patch; }
+                    const int64_t row = ((int64_t)n * gh + py) * gw + px;
+                    const int col = (ry * patch + rx) * 3;
+                    uint32_t* d = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(out) + row * K + col);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+                } else {
+                    uint8_t* orow = reinterpret_cast<uint8_t*>(out) + ((int64_t)n * H + y) * W * 3;
+                    if (C.fast) store_quad<true>(orow, x0, W, b);
+                    else store_quad<false>(orow, x0, W, b);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 18; ++i) { pa[i] = pb[i]; pb[i] = pc[i]; }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) ownb[i] = q[i];
+        }
     }
 }
 
@@ -1983,8 +2120,9 @@ int64_t chb_aug_fused_workspace_ints(int B, int H, int W, int n_tables) {
 }
 
 // one segment of a chain: ops[0..n) evaluated per output pixel of `src`; returns the number of tables it used
+// `sharp` >= 0: ops[sharp] is a Sharpness whose levels above are all pixel-local - the final launch is fused_sharp_kernel
 static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int n_ops, const FusedOp* ops, const int32_t* const* centers,
-                         int32_t* ws, int patch, hipStream_t s) {
+                         int32_t* ws, int patch, hipStream_t s, int sharp = -1) {
     FusedParams P;
     memset(&P, 0, sizeof(P));
     P.n = n_ops; P.B = B; P.H = H; P.W = W;
@@ -2019,18 +2157,17 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
         }
         if (clips) { pops[npop++] = 0; pops[npop++] = 255; }
         if (fillv >= 0 && !(clips && (fillv == 0 || fillv == 255))) pops[npop++] = fillv;
-#define CHB_FUSED_HIST2(NL, NP)                                                                                                                            \
-    do {                                                                                                                                                   \
-        if (local) hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_LOCAL, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]);   \
-        else if (rows) hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_ROWS, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]); \
-        else hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_GENERAL, NP>), grid, dim3(256), 0, s, src, part, P, fast, minmax, pops[0], pops[1], pops[2]);       \
-    } while (0)
-#define CHB_FUSED_HIST(NL)                                   \
-    do {                                                     \
-        if (npop == 0 || minmax) CHB_FUSED_HIST2(NL, 0);     \
-        else if (npop == 1) CHB_FUSED_HIST2(NL, 1);          \
-        else if (npop == 2) CHB_FUSED_HIST2(NL, 2);          \
-        else CHB_FUSED_HIST2(NL, 3);                         \
+        bool local_l = true, rows_l = true;        // launch mode of the levels under this table op
+        for (int k = 0; k < l; ++k) {
+            local_l = local_l && fused_is_local(ops[k].op);
+            rows_l = rows_l && ops[k].op != CHB_AUG_SHARPNESS && (ops[k].op != CHB_AUG_AFFINE || ops[k].f[3] == 0.0f);
+        }
+        const int np_ = minmax ? 0 : npop;
+#define CHB_FUSED_HIST(NL)                                                                                                                                  \
+    do {                                                                                                                                                    \
+        if (local_l) hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_LOCAL>), grid, dim3(256), 0, s, src, part, P, fast, minmax, np_, pops[0], pops[1], pops[2]);   \
+        else if (rows_l) hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_ROWS>), grid, dim3(256), 0, s, src, part, P, fast, minmax, np_, pops[0], pops[1], pops[2]); \
+        else hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_GENERAL>), grid, dim3(256), 0, s, src, part, P, fast, minmax, np_, pops[0], pops[1], pops[2]);       \
     } while (0)
         switch (l) {
             case 0: CHB_FUSED_HIST(0); break;
@@ -2038,12 +2175,40 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
             case 2: CHB_FUSED_HIST(2); break;
             default: CHB_FUSED_HIST(3); break;
         }
-#undef CHB_FUSED_HIST2
 #undef CHB_FUSED_HIST
         hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, part, slices, ops[l].op);
     }
     int gh = 0, gw = 0;
     if (patch) { gh = H / patch; gw = W / patch; }
+    if (sharp >= 0) {
+        bool local_b = true, rows_b = true;         // launch mode of the levels under the Sharpness
+        for (int k = 0; k < sharp; ++k) {
+            local_b = local_b && fused_is_local(ops[k].op);
+            rows_b = rows_b && ops[k].op != CHB_AUG_SHARPNESS && (ops[k].op != CHB_AUG_AFFINE || ops[k].f[3] == 0.0f);
+        }
+        const int hh = patch ? gh * patch : H;
+        const dim3 sgrid(((hh + 7) / 8 + 3) / 4, B);      // 8 output rows per wave (fused_sharp_kernel's R), 4 waves per workgroup
+#define CHB_FUSED_SHARP2(S_, PT)                                                                                                             \
+    do {                                                                                                                                     \
+        if (local_b) hipLaunchKernelGGL((fused_sharp_kernel<S_, PT, FUSED_LOCAL>), sgrid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);    \
+        else if (rows_b) hipLaunchKernelGGL((fused_sharp_kernel<S_, PT, FUSED_ROWS>), sgrid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast); \
+        else hipLaunchKernelGGL((fused_sharp_kernel<S_, PT, FUSED_GENERAL>), sgrid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);        \
+    } while (0)
+#define CHB_FUSED_SHARP(S_)                    \
+    do {                                       \
+        if (patch) CHB_FUSED_SHARP2(S_, true); \
+        else CHB_FUSED_SHARP2(S_, false);      \
+    } while (0)
+        switch (sharp) {
+            case 0: CHB_FUSED_SHARP(0); break;
+            case 1: CHB_FUSED_SHARP(1); break;
+            case 2: CHB_FUSED_SHARP(2); break;
+            default: CHB_FUSED_SHARP(3); break;
+        }
+#undef CHB_FUSED_SHARP
+#undef CHB_FUSED_SHARP2
+        return n_tables;
+    }
     const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);
 #define CHB_FUSED_FINAL2(NL, PT)                                                                                                            \
     do {                                                                                                                                    \
@@ -2084,44 +2249,43 @@ int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, 
         if (op == CHB_AUG_CUTOUT && !centers[l]) return CHB_EINVAL;
         if ((op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) && !workspace) return CHB_EINVAL;
     }
-    if (!scratch) {    // no memory for an intermediate image: the whole chain per output pixel, gathers and all
-        fused_segment(in, out, B, H, W, n_ops, ops, centers, workspace, patch, s);
+    // A Sharpness takes the levels directly under it (whatever they are) and the pixel-local levels directly above it into ITS launch
+    // (fused_sharp_kernel): `lo..end` is one launch, the Sharpness at `sh`.  A table op above stays out: its histogram pass would
+    // evaluate nine-tap windows per pixel, where the cut hands it a materialised image.
+    auto sharp_launch = [&](int lo, int& sh, int& end) {
+        sh = lo;
+        while (sh < n_ops && ops[sh].op != CHB_AUG_SHARPNESS) ++sh;
+        if (sh == n_ops) { end = n_ops; return false; }
+        end = sh + 1;
+        while (end < n_ops && fused_is_local(ops[end].op) && ops[end].op != CHB_AUG_AUTOCONTRAST && ops[end].op != CHB_AUG_EQUALIZE) ++end;
+        return true;
+    };
+    if (!scratch) {    // no memory for an intermediate image: ONE launch
+        int sh, end;
+        if (sharp_launch(0, sh, end) && end == n_ops) {       // a single Sharpness with nothing but pixel-local levels above it
+            fused_segment(in, out, B, H, W, n_ops, ops, centers, workspace, patch, s, sh);
+        } else {                                              // the whole chain per output pixel, gathers, nine-tap windows and all
+            fused_segment(in, out, B, H, W, n_ops, ops, centers, workspace, patch, s);
+        }
         CHB_LAUNCH_CHECK();
         return CHB_OK;
     }
-    // With scratch the chain is cut at its Sharpness ops: a Sharpness reads a MATERIALISED image through its own kernel (rows
-    // shared between outputs) - evaluating the levels under it at nine taps, or it under a warp's gather, costs more than the
-    // uint8 round trip (profiles/r02_augment_stage.txt).  Everything between two cuts is one launch: per output pixel one gather
-    // at most (a warp), the pixel-local ops around it applied to that pixel; without a warp, the register-lean LOCAL kernel.
-    // The last segment writes `out`, with the normalisation and the patch gather folded in.
+    // With scratch a chain that does not fit one launch (a warp or a second Sharpness ABOVE a Sharpness) is cut behind the launch of
+    // each Sharpness: what follows reads a materialised uint8 image instead of evaluating nine-tap windows under its gathers.
     const int64_t img_bytes = (int64_t)B * H * W * 3;
     const uint8_t* src = in;
     int lo = 0, n_cut = 0;
     int32_t* ws = workspace;
     while (lo < n_ops) {
-        const bool sharp = ops[lo].op == CHB_AUG_SHARPNESS;
-        int hi = lo + 1;
-        if (!sharp)
-            while (hi < n_ops && ops[hi].op != CHB_AUG_SHARPNESS) ++hi;
-        const bool last = hi == n_ops;
-        void* dst = (last && !(sharp && patch)) ? out : (void*)(scratch + (int64_t)(n_cut & 1) * img_bytes);
-        if (sharp) {
-            const int rc = chb_aug_sharpness(src, (uint8_t*)dst, B, H, W, 3, ops[lo].f[0], stream);
-            if (rc != CHB_OK) return rc;
-            if (last && patch) {      // the patch rows of the sharpened image
-                FusedOp ident;
-                memset(&ident, 0, sizeof(ident));
-                ident.op = CHB_AUG_IDENTITY;
-                const int32_t* none = nullptr;
-                fused_segment((const uint8_t*)dst, out, B, H, W, 1, &ident, &none, nullptr, patch, s);
-            }
-        } else {
-            const int nt = fused_segment(src, dst, B, H, W, hi - lo, ops + lo, centers + lo, ws, last ? patch : 0, s);
-            if (ws) ws += (int64_t)nt * fused_table_ints(B, H, W);
-        }
+        int sh, end;
+        const bool sharp = sharp_launch(lo, sh, end);
+        const bool last = end == n_ops;
+        void* dst = last ? out : (void*)(scratch + (int64_t)(n_cut & 1) * img_bytes);
+        const int nt = fused_segment(src, dst, B, H, W, end - lo, ops + lo, centers + lo, ws, last ? patch : 0, s, sharp ? sh - lo : -1);
+        if (ws) ws += (int64_t)nt * fused_table_ints(B, H, W);
         src = (const uint8_t*)dst;
         ++n_cut;
-        lo = hi;
+        lo = end;
     }
     CHB_LAUNCH_CHECK();
     return CHB_OK;
