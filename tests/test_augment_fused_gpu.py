@@ -144,6 +144,29 @@ def test_full_size_batches(size, batch):
         assert torch.equal(rows, K.normalize_patchify(out, 16, "tf")), ops
 
 
+@pytest.mark.parametrize("shape", [(2, 21, 260, 3), (2, 18, 250, 3), (1, 9, 516, 3)])
+def test_wide_rows_sharpness_windows_and_row_warps(shape):
+    """Rows wider than one 62-quad window of the Sharpness launch (the halo crosses a window seam), W % 4 != 0, warps whose source
+    row does not depend on x (one run per quad, also nested and under / above a Sharpness), patch rows that crop the image."""
+    from chambers_amd import augmentations as aug
+    from chambers_amd import kernels as K
+    x = _img(shape, 83)
+    x[0, :, :40] = 200                      # a flat area: ties and fill-like values
+    g = np.random.Generator(np.random.PCG64(89))
+    chains = [(9, 6), (10, 6), (7, 6), (8, 6), (15, 6), (2, 6), (6, 2), (6, 14), (6, 5), (6, 9), (6, 1), (1, 6), (9, 10), (7, 9), (10, 7), (7, 7),
+              (9, 6, 3), (2, 9, 6), (7, 14, 6, 4), (6, 3, 6), (10, 1, 9)]
+    for ops in chains:
+        layer = aug.RandAugment(len(ops), 9)
+        for trial in range(2):              # both signs turn up
+            dec = _decisions(g, ops, *shape[:3])
+            plan = layer.plan(shape, dec)
+            ref = A.rand_augment(x, len(ops), 9, dec)
+            _eq(K.aug_fused(_dev(x), plan, scratch=True), ref, "cut %s" % (ops,))
+            _eq(K.aug_fused(_dev(x), plan, scratch=False), ref, "uncut %s" % (ops,))
+            rows = K.aug_fused(_dev(x), plan, patch=4)
+            assert torch.equal(rows.cpu().view(torch.int16), _patch_rows(ref, 4).view(torch.int16)), ops
+
+
 def test_uncut_chains_equal_cut_chains():
     """scratch=False: a Sharpness above other ops evaluates them at its nine taps instead of reading a materialised image - the
     same bytes either way (and the route a C caller without scratch memory takes)."""
