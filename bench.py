@@ -358,14 +358,14 @@ def main():
         x, plan = images, None
         if not args.no_augment:
             if args.elementwise:
-                # per-image decisions (elementwise=True, the reference's tf.map_fn mode): one dispatch launch per slot, then the
-                # normalise + patchify pass of the engine
+                # per-image decisions (elementwise=True, the reference's tf.map_fn mode): every image's own chain, evaluated inside the
+                # engine's normalise + patchify pass like the batch-shared chain
                 if args.augment == "autoaugment":
-                    x = autoaug(images, training=True, decision=[autoaugment_decision() for _ in range(args.batch)])
+                    plan = autoaug.items_plan(images.shape, [autoaugment_decision() for _ in range(args.batch)])
                 else:
-                    x = randaug(images, training=True, decisions=[[{"op": int(gd.integers(0, 16)), "negate": bool(gd.uniform() < 0.5),
-                                                                    "centers": (int(gd.integers(0, hw[0])), int(gd.integers(0, hw[1])))}
-                                                                   for _ in range(2)] for _ in range(args.batch)])
+                    plan = randaug.items_plan(images.shape, [[{"op": int(gd.integers(0, 16)), "negate": bool(gd.uniform() < 0.5),
+                                                              "centers": (int(gd.integers(0, hw[0])), int(gd.integers(0, hw[1])))}
+                                                             for _ in range(2)] for _ in range(args.batch)])
             elif args.unfused_augment:
                 x = (autoaug(images, training=True, decision=autoaugment_decision()) if args.augment == "autoaugment" else
                      randaug(images, training=True, decisions=draw_randaugment_decisions(gd, 2, args.batch, *hw)))

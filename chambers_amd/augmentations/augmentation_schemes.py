@@ -184,22 +184,30 @@ class AutoAugment(Layer):
 
     def _elementwise(self, inputs, decisions):
         """elementwise=True (:135, RandomChoice :563-570): every image draws its own sub-policy, its two chance draws and its
-        sign draws.  The two steps of the 25 sub-policies are two launches of the per-image dispatch kernel."""
+        sign draws.  The two steps of the 25 sub-policies run as one launch, each workgroup its own image's pair (chb_aug_fused_items)."""
         from .. import kernels as K
         b = inputs.shape[0]
         if b == 0:
             return inputs
         h, w = int(inputs.shape[1]), int(inputs.shape[2])
+        return K.aug_fused_items(inputs, self.elementwise_items(b, h, w, decisions))
+
+    def elementwise_items(self, b, h, w, decisions=None):
+        """[2, B] op records of one elementwise call: every image its own sub-policy, chance draws and signs."""
+        from .. import kernels as K
         items = np.zeros((2, b), dtype=K.AUG_ITEM_DTYPE)
         for n in range(b):
             d = decisions[n] if decisions is not None else self.draw_decision()
             seq = self.transforms[int(d["policy"])]
             for j, chance in enumerate(seq.layers):
                 items[j, n] = chance.dispatch_item(h, w, apply=bool(d["apply"][j]), negate=bool(d["negate"][j]))
-        x = inputs
-        for j in range(2):
-            x = K.aug_dispatch(x, items[j])
-        return x
+        return items
+
+    def items_plan(self, input_shape, decisions=None):
+        """The elementwise call resolved to per-image op records (kernels.AugItemsPlan) - what ViTEngine.forward(..., augment=plan)
+        evaluates inside its normalise + patchify pass."""
+        from .. import kernels as K
+        return K.AugItemsPlan(self.elementwise_items(int(input_shape[0]), int(input_shape[1]), int(input_shape[2]), decisions))
 
     def compute_output_shape(self, input_shape):
         return self._transform.compute_output_shape(input_shape)
@@ -246,11 +254,22 @@ class RandAugment(Layer):
         choices, kws = split(decisions)
         return self._transform(inputs, choices=choices, slot_kwargs=kws)
 
+    def items_plan(self, input_shape, decisions=None):
+        """The elementwise call resolved to per-image op records (kernels.AugItemsPlan; decisions: one list of n_transforms dicts
+        per image, centers = (cy, cx)) - what ViTEngine.forward(..., augment=plan) evaluates inside its normalise + patchify pass."""
+        from .. import kernels as K
+        b, h, w = int(input_shape[0]), int(input_shape[1]), int(input_shape[2])
+        if decisions is None:
+            return K.AugItemsPlan(self._transform.elementwise_items(b, h, w))
+        choices = [[int(d["op"]) for d in ds] for ds in decisions]
+        kws = [[{k: v for k, v in d.items() if k != "op"} for d in ds] for ds in decisions]
+        return K.AugItemsPlan(self._transform.elementwise_items(b, h, w, choices, kws))
+
     def plan(self, input_shape, decisions=None):
         """The batch-shared call resolved to op records (kernels.AugPlan) - what ViTEngine.forward(..., augment=plan) fuses
         into its normalise + patchify pass."""
         if self.elementwise:
-            raise ValueError("plan() describes the batch-shared mode; elementwise=True runs the per-image dispatch kernel")
+            raise ValueError("plan() describes the batch-shared mode; elementwise=True resolves to per-image records: items_plan()")
         if decisions is None:
             return self._transform.plan(input_shape)
         return self._transform.plan(input_shape, [int(d["op"]) for d in decisions], [{k: v for k, v in d.items() if k != "op"} for d in decisions])

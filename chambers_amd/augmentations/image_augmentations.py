@@ -495,8 +495,9 @@ class RandomChoice(Layer):
     def _elementwise(self, inputs, choices, slot_kwargs):
         """tf.map_fn over batch-1 tensors (:565-567): every image draws its own transform index per slot, and the chosen
         transform sees a batch of one (its sign draw, cutout centre and Contrast's constant are per image).  When every
-        transform can describe itself as a record of the per-image dispatch kernel, a slot is ONE launch for the whole batch
-        (chb_aug_dispatch); transforms that cannot (user-supplied layers) take the image-by-image route."""
+        transform can describe itself as an op record, the whole call is ONE launch for the whole batch, each workgroup
+        evaluating its own image's chain (chb_aug_fused_items; chains longer than the fused kernels hold: one dispatch launch per
+        slot, chb_aug_dispatch); transforms that cannot (user-supplied layers) take the image-by-image route."""
         b = inputs.shape[0]
         if b == 0:
             return inputs
@@ -508,16 +509,24 @@ class RandomChoice(Layer):
                 outs.append(self._random_transforms(inputs[n:n + 1], ch, sk))
             return K.concat_batch(outs)
         h, w = int(inputs.shape[1]), int(inputs.shape[2])
-        items = np.zeros((self.n_transforms, b), dtype=K.AUG_ITEM_DTYPE)
-        for n in range(b):                    # draw order of the reference's map_fn body: image by image, slot by slot
-            for i in range(self.n_transforms):
-                idx = int(rng.host_generator().integers(0, len(self.transforms))) if choices is None else int(choices[n][i])
-                kw = {} if slot_kwargs is None else dict(slot_kwargs[n][i])
-                items[i, n] = self.transforms[idx].dispatch_item(h, w, **kw)
+        items = self.elementwise_items(b, h, w, choices, slot_kwargs)
+        if self.n_transforms <= K.FUSED_MAX_OPS:
+            return K.aug_fused_items(inputs, items)        # every image's chain in one launch (chb_aug_fused_items)
         x = inputs
         for i in range(self.n_transforms):
             x = K.aug_dispatch(x, items[i])
         return x
+
+    def elementwise_items(self, b, h, w, choices=None, slot_kwargs=None):
+        """[n_transforms, B] op records of one elementwise call, drawn in the order of the reference's map_fn body: image by image,
+        slot by slot (the transform index, then whatever the chosen transform draws)."""
+        items = np.zeros((self.n_transforms, b), dtype=K.AUG_ITEM_DTYPE)
+        for n in range(b):
+            for i in range(self.n_transforms):
+                idx = int(rng.host_generator().integers(0, len(self.transforms))) if choices is None else int(choices[n][i])
+                kw = {} if slot_kwargs is None else dict(slot_kwargs[n][i])
+                items[i, n] = self.transforms[idx].dispatch_item(h, w, **kw)
+        return items
 
     def _random_transforms(self, inputs, choices=None, slot_kwargs=None):
         if self._can_fuse(inputs):

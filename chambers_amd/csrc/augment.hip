@@ -1212,7 +1212,16 @@ struct FusedParams {
     const int32_t* lut[CHB_FUSED_MAX_OPS];        // level's [B][3][256] table (AutoContrast / Equalize), else NULL
     const int32_t* centers[CHB_FUSED_MAX_OPS];    // level's [B][2] cutout centres (cy, cx), else NULL
     int32_t B, H, W;
+    const FusedOp* items;                          // NULL, or per-image records [n][B] (elementwise schemes): they replace ops[]
 };
+
+// the op record of level l for image n: the launch's own, or - elementwise schemes (image_augmentations.py:563-570), every image its
+// own chain - the image's record in device memory.  A workgroup works on one image, so either way this is a scalar load.
+template <bool ITEMS>
+__device__ __forceinline__ const FusedOp& fused_op(const FusedParams& P, int n, int l) {
+    if (ITEMS) return P.items[(int64_t)l * P.B + n];
+    return P.ops[l];
+}
 
 // one unaligned dword per pixel (the memory pipeline, not HBM, bounds the gathers: a byte load costs what a dword load costs);
 // the last pixel of the image steps back a byte instead of reading past the allocation (a one-pixel image loads bytes)
@@ -1293,16 +1302,17 @@ __device__ __forceinline__ bool affine_source(const FusedOp& o, int W, int H, in
     return ok;
 }
 
+template <bool ITEMS = false>
 __device__ __forceinline__ bool cutout_inside(const FusedParams& P, int l, int n, int y, int x) {
-    const int cy = P.centers[l][2 * n], cx = P.centers[l][2 * n + 1], half = P.ops[l].i2;
+    const int cy = P.centers[l][2 * n], cx = P.centers[l][2 * n + 1], half = fused_op<ITEMS>(P, n, l).i2;
     return (y >= max(0, cy - half)) && (y < min(P.H, cy + half)) && (x >= max(0, cx - half)) && (x < min(P.W, cx + half));
 }
 
 // ---- one pixel of level L (gathers: below a warp, and the two edge columns of a Sharpness window) ----
-template <int L>
+template <int L, bool ITEMS = false>
 struct FusedEval {
     static __device__ uint32_t at(const FusedParams& P, const FusedCtx& C, int y, int x) {
-        const FusedOp& o = P.ops[L];
+        const FusedOp& o = fused_op<ITEMS>(P, C.n, L);
         const int op = o.op;     // the same for every thread of the launch
         if (op == CHB_AUG_SHARPNESS) {
             const bool interior = (y >= 1) && (y < P.H - 1) && (x >= 1) && (x < P.W - 1);
@@ -1314,7 +1324,7 @@ struct FusedEval {
 #pragma unroll 1
             for (int t = interior ? 0 : 4; t < (interior ? 9 : 5); ++t) {      // row-major taps; a border pixel reads its centre only
                 const int ky = t / 3 - 1, kx = t % 3 - 1;
-                const uint32_t v = FusedEval<L - 1>::at(P, C, y + ky, x + kx);
+                const uint32_t v = FusedEval<L - 1, ITEMS>::at(P, C, y + ky, x + kx);
                 const float w = (t == 4) ? k5 : k1;
                 if (t == 4) centre = v;
                 acc[0] = acc[0] + (float)(v & 0xff) * w;
@@ -1336,10 +1346,10 @@ struct FusedEval {
             keep = affine_source(o, P.W, P.H, x, y, sx, sy);
             konst = ((uint32_t)(o.i0 & 0xff)) * 0x010101u;
         } else if (op == CHB_AUG_CUTOUT) {
-            keep = !cutout_inside(P, L, C.n, y, x);
+            keep = !cutout_inside<ITEMS>(P, L, C.n, y, x);
             konst = ((uint32_t)(o.i3 & 0xff)) * 0x010101u;
         }
-        const uint32_t v = FusedEval<L - 1>::at(P, C, sy, sx);
+        const uint32_t v = FusedEval<L - 1, ITEMS>::at(P, C, sy, sx);
         if (!keep) return konst;
         if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
             const uint8_t* lut = C.lut + L * 768;
@@ -1348,8 +1358,8 @@ struct FusedEval {
         return px_pointwise(op, v, o);
     }
 };
-template <>
-struct FusedEval<-1> {
+template <bool ITEMS>
+struct FusedEval<-1, ITEMS> {
     static __device__ __forceinline__ uint32_t at(const FusedParams& P, const FusedCtx& C, int y, int x) {
         return px_load(C.img, P.H, P.W, y, x);
     }
@@ -1359,15 +1369,15 @@ struct FusedEval<-1> {
 // up as one 12-byte quad, so every pointwise / table level is the vector code of the quad path instead of one byte-wise evaluation
 // per pixel (r03: a pixel-local op UNDER a warp cost 30 us more than the same op above it).  Sharpness under a warp keeps the
 // per-pixel evaluation (nine taps around each of four unrelated positions).
-template <int L>
+template <int L, bool ITEMS = false>
 struct FusedGather {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, const int (&ys)[4], const int (&xs)[4], uint8_t (&b)[12]) {
-        const FusedOp& o = P.ops[L];
+        const FusedOp& o = fused_op<ITEMS>(P, C.n, L);
         const int op = o.op;
         if (op == CHB_AUG_SHARPNESS) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t v = FusedEval<L>::at(P, C, ys[i], xs[i]);
+                const uint32_t v = FusedEval<L, ITEMS>::at(P, C, ys[i], xs[i]);
                 b[3 * i + 0] = v & 0xff; b[3 * i + 1] = (v >> 8) & 0xff; b[3 * i + 2] = (v >> 16) & 0xff;
             }
             return;
@@ -1377,7 +1387,7 @@ struct FusedGather {
             bool ok[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) ok[i] = affine_source(o, P.W, P.H, xs[i], ys[i], x2[i], y2[i]);
-            FusedGather<L - 1>::at(P, C, y2, x2, b);
+            FusedGather<L - 1, ITEMS>::at(P, C, y2, x2, b);
             const uint8_t fill = (uint8_t)(o.i0 & 0xff);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -1385,7 +1395,7 @@ struct FusedGather {
                 for (int c = 0; c < 3; ++c) b[3 * i + c] = ok[i] ? b[3 * i + c] : fill;
             return;
         }
-        FusedGather<L - 1>::at(P, C, ys, xs, b);
+        FusedGather<L - 1, ITEMS>::at(P, C, ys, xs, b);
         if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
             const uint8_t* lut = C.lut + L * 768;
 #pragma unroll
@@ -1393,7 +1403,7 @@ struct FusedGather {
         } else if (op == CHB_AUG_CUTOUT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool inside = cutout_inside(P, L, C.n, ys[i], xs[i]);
+                const bool inside = cutout_inside<ITEMS>(P, L, C.n, ys[i], xs[i]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
             }
@@ -1402,8 +1412,8 @@ struct FusedGather {
         }
     }
 };
-template <>
-struct FusedGather<-1> {
+template <bool ITEMS>
+struct FusedGather<-1, ITEMS> {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, const int (&ys)[4], const int (&xs)[4], uint8_t (&b)[12]) {
 #pragma unroll      // the four gathers in flight together
         for (int i = 0; i < 4; ++i) {
@@ -1421,21 +1431,24 @@ struct FusedGather<-1> {
 //                 pixel of this H x W): the source of (x, y) is (x + d(y), r(y)), so a quad reads ONE run of four pixels - the
 //                 levels underneath are evaluated as a quad at the shifted start (any x0, also outside the row: masked on the way
 //                 up), one affine evaluation per quad instead of four and no per-pixel gathers;
-//   FUSED_GENERAL everything else (per-pixel gathers below a warp, windows below a Sharpness).
-constexpr int FUSED_GENERAL = 0, FUSED_LOCAL = 1, FUSED_ROWS = 2;
+//   FUSED_GENERAL everything else (per-pixel gathers below a warp, windows below a Sharpness);
+//   FUSED_ITEMS   as FUSED_GENERAL, the op records being each image's own (FusedParams::items: elementwise schemes).
+constexpr int FUSED_GENERAL = 0, FUSED_LOCAL = 1, FUSED_ROWS = 2, FUSED_ITEMS = 3;
 struct __attribute__((aligned(4))) u32x4_a4 { uint32_t w[4]; };
 
 template <int L, int MODE>
 struct FusedQuad {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
-        const FusedOp& o = P.ops[L];
+        constexpr bool ITEMS = MODE == FUSED_ITEMS;            // per-image records; otherwise as FUSED_GENERAL
+        constexpr bool GENERAL = MODE == FUSED_GENERAL || ITEMS;
+        const FusedOp& o = fused_op<ITEMS>(P, C.n, L);
         const int op = o.op;
-        if (MODE == FUSED_GENERAL && op == CHB_AUG_AFFINE) {
+        if (GENERAL && op == CHB_AUG_AFFINE) {
             int ys[4], xs[4];
             bool ok[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) ok[i] = affine_source(o, P.W, P.H, x0 + i, y, xs[i], ys[i]);
-            FusedGather<L - 1>::at(P, C, ys, xs, b);
+            FusedGather<L - 1, ITEMS>::at(P, C, ys, xs, b);
             const uint8_t fill = (uint8_t)(o.i0 & 0xff);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -1443,7 +1456,7 @@ struct FusedQuad {
                 for (int c = 0; c < 3; ++c) b[3 * i + c] = ok[i] ? b[3 * i + c] : fill;
             return;
         }
-        if (MODE == FUSED_GENERAL && op == CHB_AUG_SHARPNESS) {
+        if (GENERAL && op == CHB_AUG_SHARPNESS) {
             // window rows y-1..y+1, columns x0-1..x0+4: three quads + the two edge columns, 18 evaluations for 4 outputs; the
             // taps are summed in row-major order, so the rows can be folded into the 12 sums as they arrive
             const bool yin = (y >= 1) && (y < P.H - 1);
@@ -1457,8 +1470,8 @@ struct FusedQuad {
                 uint8_t w[18];
                 uint8_t q[12];
                 FusedQuad<L - 1, MODE>::at(P, C, y + r - 1, x0, q);
-                const uint32_t lft = (yin && x0 >= 1) ? FusedEval<L - 1>::at(P, C, y + r - 1, x0 - 1) : 0u;
-                const uint32_t rgt = (yin && x0 + 4 < P.W) ? FusedEval<L - 1>::at(P, C, y + r - 1, x0 + 4) : 0u;
+                const uint32_t lft = (yin && x0 >= 1) ? FusedEval<L - 1, ITEMS>::at(P, C, y + r - 1, x0 - 1) : 0u;
+                const uint32_t rgt = (yin && x0 + 4 < P.W) ? FusedEval<L - 1, ITEMS>::at(P, C, y + r - 1, x0 + 4) : 0u;
                 w[0] = lft & 0xff; w[1] = (lft >> 8) & 0xff; w[2] = (lft >> 16) & 0xff;
 #pragma unroll
                 for (int i = 0; i < 12; ++i) w[3 + i] = q[i];
@@ -1497,7 +1510,7 @@ struct FusedQuad {
         } else if (op == CHB_AUG_CUTOUT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool inside = cutout_inside(P, L, C.n, y, x0 + i);
+                const bool inside = cutout_inside<ITEMS>(P, L, C.n, y, x0 + i);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
             }
@@ -1520,7 +1533,7 @@ struct FusedQuad<-1, MODE> {
 template <int L>
 struct FusedRow {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, const int (&xs)[4], uint8_t (&b)[12]) {
-        const FusedOp& o = P.ops[L];
+        const FusedOp& o = fused_op<false>(P, C.n, L);
         const int op = o.op;
         if (op == CHB_AUG_AFFINE) {             // f[3] == 0 (host): the source row does not depend on x
             const float fy = (float)y;
@@ -1606,9 +1619,10 @@ __device__ __forceinline__ void fused_top_quad(const FusedParams& P, const Fused
     }
 }
 
+template <bool ITEMS = false>
 __device__ __forceinline__ void fused_stage_luts(const FusedParams& P, int n, uint8_t* lutS) {
     for (int l = 0; l < P.n; ++l)       // uniform
-        if (P.lut[l])
+        if (P.lut[l] && (fused_op<ITEMS>(P, n, l).op == CHB_AUG_AUTOCONTRAST || fused_op<ITEMS>(P, n, l).op == CHB_AUG_EQUALIZE))
             for (int i = threadIdx.x; i < 768; i += blockDim.x) lutS[l * 768 + i] = (uint8_t)P.lut[l][(int64_t)n * 768 + i];
     __syncthreads();
 }
@@ -1625,12 +1639,17 @@ __device__ __forceinline__ int hist_slot(int bin) { return bin ^ ((bin >> 3) & 7
 template <int NLEV, int MODE>
 __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ part, FusedParams P, int fast,
                                                          int minmax, int npop, int pop0, int pop1, int pop2) {
+    if (MODE == FUSED_ITEMS) {      // per-image chains: this image's op at the level - a table op at all, and which
+        const int op = fused_op<true>(P, blockIdx.y, NLEV < CHB_FUSED_MAX_OPS ? NLEV : 0).op;
+        if (op != CHB_AUG_AUTOCONTRAST && op != CHB_AUG_EQUALIZE) return;
+        minmax = op == CHB_AUG_AUTOCONTRAST ? 1 : 0;
+    }
     __shared__ int32_t h[768];
     int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) h[i] = 0;
     const int n = blockIdx.y;
-    fused_stage_luts(P, n, lutS);
+    fused_stage_luts<MODE == FUSED_ITEMS>(P, n, lutS);
     const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
     const int wq = (P.W + 3) >> 2;
     const int nq = P.H * wq;
@@ -1704,7 +1723,7 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
                                                           int fast) {
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
     const int n = blockIdx.y;
-    fused_stage_luts(P, n, lutS);
+    fused_stage_luts<MODE == FUSED_ITEMS>(P, n, lutS);
     const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = PATCH ? (gw * patch) >> 2 : (P.W + 3) >> 2;
@@ -1885,11 +1904,17 @@ __global__ void __launch_bounds__(256) fused_sharp_kernel(const uint8_t* __restr
 
 // table from the histogram of one (image, channel): the batch-shared op of level `lvl` (same code as lut_build_kernel); the histogram
 // is the sum of the `slices` partial tables fused_hist_kernel left for the image (AutoContrast: min / max over their slots 0 / 1)
-__global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ tables, const int32_t* __restrict__ part, int slices, int op) {
+// (items != NULL: the image's own op at the level, [B] records; an image without a table op there is skipped)
+__global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ tables, const int32_t* __restrict__ part, int slices, int op,
+                                                        const FusedOp* __restrict__ items = nullptr) {
     __shared__ int32_t s[256];
     __shared__ int32_t first_nz, last_nz;
     __shared__ int32_t hsave[256];
     const int n = blockIdx.x / 3, c = blockIdx.x - 3 * n;
+    if (items) {
+        op = items[n].op;
+        if (op != CHB_AUG_AUTOCONTRAST && op != CHB_AUG_EQUALIZE) return;
+    }
     const int t = threadIdx.x;
     const int32_t* p0 = part + (int64_t)n * slices * 768 + c * 256 + t;
     int32_t mine = 0;
@@ -2176,7 +2201,7 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
             default: CHB_FUSED_HIST(3); break;
         }
 #undef CHB_FUSED_HIST
-        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, part, slices, ops[l].op);
+        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, part, slices, ops[l].op, (const FusedOp*)nullptr);
     }
     int gh = 0, gw = 0;
     if (patch) { gh = H / patch; gw = W / patch; }
@@ -2287,6 +2312,63 @@ int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, 
         ++n_cut;
         lo = end;
     }
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+// Per-image chains (the schemes' elementwise=True mode, image_augmentations.py:563-570 / augmentation_schemes.py:135): items_dev holds
+// one FusedOp per (level, image), [n_ops][B].  One final launch for the whole batch (+ a histogram pass and a table launch per level at
+// which some image has an AutoContrast / Equalize: `table_levels` bit l), every workgroup evaluating its own image's chain.
+int chb_aug_fused_items(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev, const int32_t* const* centers_dev,
+                        int table_levels, int32_t* workspace, int patch, void* stream) {
+    if (B == 0) return CHB_OK;
+    if (!in || !out || !items_dev || B < 0 || H <= 0 || W <= 0 || n_ops < 1 || n_ops > CHB_FUSED_MAX_OPS || patch < 0 || (patch & 3)) return CHB_EINVAL;
+    if ((int64_t)H * W * 3 >= 2147483647LL - 4 || B > 65535) return CHB_EUNSUPPORTED;
+    if (patch && (H / patch == 0 || W / patch == 0)) return CHB_EINVAL;
+    if ((table_levels & ((1 << n_ops) - 1)) && !workspace) return CHB_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const FusedOp* items = (const FusedOp*)items_dev;
+    FusedParams P;
+    memset(&P, 0, sizeof(P));
+    P.n = n_ops; P.B = B; P.H = H; P.W = W;
+    P.items = items;
+    const int fast = ((W & 3) == 0 && !((uintptr_t)in & 3) && (patch || !((uintptr_t)out & 3))) ? 1 : 0;
+    int n_tables = 0;
+    for (int l = 0; l < n_ops; ++l) {
+        P.centers[l] = centers_dev ? centers_dev[l] : nullptr;          // the [B,2] cutout centres of the level (images without a CutOut there ignore them)
+        if (table_levels & (1 << l)) P.lut[l] = workspace + (int64_t)(n_tables++) * fused_table_ints(B, H, W);
+    }
+    const int slices = slices_for((int64_t)H * W * 3, B);
+    for (int l = 0; l < n_ops; ++l) {
+        if (!P.lut[l]) continue;
+        int32_t* t = const_cast<int32_t*>(P.lut[l]);
+        int32_t* part = t + (int64_t)B * 768;
+        const dim3 grid(slices, B);
+#define CHB_ITEMS_HIST(NL) hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_ITEMS>), grid, dim3(256), 0, s, in, part, P, fast, 0, 0, -2, -2, -2)
+        switch (l) {
+            case 0: CHB_ITEMS_HIST(0); break;
+            case 1: CHB_ITEMS_HIST(1); break;
+            case 2: CHB_ITEMS_HIST(2); break;
+            default: CHB_ITEMS_HIST(3); break;
+        }
+#undef CHB_ITEMS_HIST
+        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, part, slices, 0, items + (int64_t)l * B);
+    }
+    int gh = 0, gw = 0;
+    if (patch) { gh = H / patch; gw = W / patch; }
+    const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);
+#define CHB_ITEMS_FINAL(NL)                                                                                                                            \
+    do {                                                                                                                                               \
+        if (patch) hipLaunchKernelGGL((fused_final_kernel<NL, true, FUSED_ITEMS>), grid, dim3(256), 0, s, in, out, P, patch, gh, gw, fast);  \
+        else hipLaunchKernelGGL((fused_final_kernel<NL, false, FUSED_ITEMS>), grid, dim3(256), 0, s, in, out, P, patch, gh, gw, fast);       \
+    } while (0)
+    switch (n_ops) {
+        case 1: CHB_ITEMS_FINAL(1); break;
+        case 2: CHB_ITEMS_FINAL(2); break;
+        case 3: CHB_ITEMS_FINAL(3); break;
+        default: CHB_ITEMS_FINAL(4); break;
+    }
+#undef CHB_ITEMS_FINAL
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

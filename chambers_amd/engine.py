@@ -663,12 +663,13 @@ class ViTEngine:
         if not prepatched:
             if tuple(images_u8.shape) != (self.B, cfg.image_size[0], cfg.image_size[1], 3):
                 raise ValueError("expected images of shape %s, got %s" % ((self.B,) + cfg.image_size + (3,), tuple(images_u8.shape)))
+            per_image = isinstance(augment, K.AugItemsPlan)       # an elementwise scheme: every image its own chain
             if augment is not None and len(augment) and cfg.norm_mode == "tf":
-                # scheme chain + normalise + patch gather in one pass over the uint8 batch (chb_aug_fused)
-                K.aug_fused(images_u8, augment, patch=cfg.patch_size, out=self.patches)
+                # scheme chain + normalise + patch gather in one pass over the uint8 batch (chb_aug_fused / chb_aug_fused_items)
+                (K.aug_fused_items if per_image else K.aug_fused)(images_u8, augment, patch=cfg.patch_size, out=self.patches)
             else:
                 if augment is not None and len(augment):
-                    images_u8 = K.aug_fused(images_u8, augment)
+                    images_u8 = (K.aug_fused_items if per_image else K.aug_fused)(images_u8, augment)
                 K.normalize_patchify(images_u8, cfg.patch_size, cfg.norm_mode, out=self.patches)
         x0 = self.xs[0]
         K.gemm_nt(self.patches, self.wbt("patch_embeddings/embedding/kernel"), x0, m=self.Mpatch,

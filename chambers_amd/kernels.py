@@ -204,6 +204,73 @@ def aug_fused(x, plan, patch=None, out=None, scratch=True):
     return out
 
 
+class AugItemsPlan:
+    """Per-image chains of an elementwise scheme: `items` = numpy [n_slots, B] of AUG_ITEM_DTYPE (what the transforms' dispatch_item
+    returns).  ViTEngine.forward(..., augment=AugItemsPlan) evaluates them inside its normalise + patchify pass.  The device copy of
+    the records is made on first use and kept (a plan replayed from a HIP graph uploads nothing)."""
+
+    def __init__(self, items):
+        self.items = np.ascontiguousarray(items, dtype=AUG_ITEM_DTYPE)
+        if self.items.ndim != 2:
+            raise ValueError("expected [n_slots, B] op records, got shape %s" % (self.items.shape,))
+        self._resident = None
+
+    def __len__(self):
+        return int(self.items.shape[0])
+
+    def resident(self, device):
+        """(device records [n*B, 48] uint8, per-level cutout-centre tensors or None, table-level bit mask)"""
+        if self._resident is None or self._resident[0].device != device:
+            items = self.items
+            n, b = items.shape
+            recs = np.zeros((n, b), dtype=FUSED_OP_DTYPE)
+            recs["op"] = items["op"]
+            recs["i"] = items["i"]
+            recs["f"] = items["f"][..., :6]
+            centers, tables = [], 0
+            for l in range(n):
+                ops = items[l]["op"]
+                if np.isin(ops, (_lib.AUG_AUTOCONTRAST, _lib.AUG_EQUALIZE)).any():
+                    tables |= 1 << l
+                # the dispatch record carries a CutOut's centre in i0, i1; the chain evaluators read a [B,2] table
+                centers.append(_upload(np.ascontiguousarray(items[l]["i"][:, :2], dtype=np.int32), device) if (ops == _lib.AUG_CUTOUT).any() else None)
+            self._resident = (_upload(recs.view(np.uint8).reshape(n * b, FUSED_OP_DTYPE.itemsize), device), centers, tables)
+        return self._resident
+
+
+def aug_fused_items(x, items, patch=None, out=None):
+    """The whole per-image chain in ONE launch (chb_aug_fused_items; + a histogram pass and a table launch per slot in which some
+    image drew AutoContrast / Equalize).  items: [n_slots, B] AUG_ITEM_DTYPE or an AugItemsPlan; patch as for aug_fused."""
+    x = _u8_nhwc(x)
+    b, h, w, c = x.shape
+    if c != 3:
+        raise ValueError("per-image chains handle RGB batches (the schemes' InputSpec), got %d channels" % c)
+    plan = items if isinstance(items, AugItemsPlan) else AugItemsPlan(items)
+    n = len(plan)
+    if plan.items.shape[1] != b or not 1 <= n <= FUSED_MAX_OPS:
+        raise ValueError("expected [1..%d, %d] op records, got %s" % (FUSED_MAX_OPS, b, plan.items.shape))
+    dev_items, centers, tables = plan.resident(x.device)
+    cptr = (ctypes.c_void_p * n)()
+    for l, cen in enumerate(centers):
+        if cen is not None:
+            cptr[l] = cen.data_ptr()
+    nt = bin(tables).count("1")
+    ws = torch.empty(_lib.aug_fused_workspace_ints(b, h, w, nt), dtype=torch.int32, device=x.device) if nt and b else None
+    if patch is None:
+        out = torch.empty_like(x) if out is None else out
+        if out.shape != x.shape or out.dtype != torch.uint8 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous uint8 tensor shaped like the input")
+    else:
+        rows = b * (h // patch) * (w // patch)
+        if out is None:
+            out = torch.empty((rows, patch * patch * 3), dtype=torch.bfloat16, device=x.device)
+        if out.dtype != torch.bfloat16 or out.numel() < rows * patch * patch * 3 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous bf16 buffer of at least %d patch rows" % rows)
+    _lib.call("chb_aug_fused_items", _lib.ptr(x), _lib.ptr(out), b, h, w, n, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables,
+              _lib.ptr(ws), 0 if patch is None else int(patch), _s())
+    return out
+
+
 def concat_batch(parts):
     """Batch-axis concatenation of same-shaped image tensors by device-to-device copies into one allocation (the
     image-by-image route of elementwise schemes with user-supplied transforms)."""

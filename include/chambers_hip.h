@@ -323,6 +323,14 @@ int chb_aug_dispatch(const uint8_t* in, uint8_t* out, int B, int H, int W, const
 #define CHB_FUSED_MAX_OPS 4
 int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* ops_host,
                   const int32_t* const* centers_dev, int32_t* workspace, uint8_t* scratch, int patch, void* stream);
+/* The same stage for the schemes' elementwise=True mode (image_augmentations.py:563-570, augmentation_schemes.py:135: tf.map_fn over
+ * batch-1 tensors - every image draws its own ops, signs, cutout centre, and Contrast's constant is its own H*W/256).  items_dev:
+ * DEVICE records, one per (level, image), [n_ops][B], laid out as chb_aug_fused's host records.  centers_dev[l]: device int32 [B,2]
+ * for the images with a CutOut at level l (NULL if none).  table_levels: bit l set if some image has an AutoContrast / Equalize at
+ * level l; workspace: chb_aug_fused_workspace_ints(B, H, W, popcount(table_levels)) int32, uninitialised.  One launch for the batch
+ * (+ a histogram pass and a table launch per set bit); out as for chb_aug_fused.  Bit-identical to the ops applied image by image. */
+int chb_aug_fused_items(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev,
+                        const int32_t* const* centers_dev, int table_levels, int32_t* workspace, int patch, void* stream);
 /* int32 elements of chb_aug_fused's workspace for a chain with n_tables AutoContrast / Equalize ops (0 for none): host arithmetic only. */
 int64_t chb_aug_fused_workspace_ints(int B, int H, int W, int n_tables);
 

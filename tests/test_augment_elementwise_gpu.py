@@ -159,3 +159,33 @@ def test_elementwise_golden_fixture():
         _eq(out, ref["randaugment_elementwise_" + tag], "golden randaugment " + tag)
         out = aug.AutoAugment(elementwise=True)(x, training=True, decision=gen.elementwise_autoaugment_decisions(shape))
         _eq(out, ref["autoaugment_elementwise_" + tag], "golden autoaugment " + tag)
+
+
+def test_per_image_chains_as_patch_rows_and_through_the_engine():
+    """chb_aug_fused_items with patch > 0 = the "tf"-normalised patch rows of the per-image chains; ViTEngine.forward(images,
+    augment=items_plan) = forward(scheme(images))."""
+    from chambers_amd import augmentations as aug
+    from chambers_amd import kernels as K
+    from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
+    shape = (6, 64, 48, 3)
+    x = _img(shape, 5)
+    g = np.random.Generator(np.random.PCG64(7))
+    for trial in range(6):
+        dec = [[{"op": int(g.integers(0, 16)), "negate": bool(g.uniform() < 0.5), "centers": (int(g.integers(0, shape[1])), int(g.integers(0, shape[2])))}
+                for _ in range(2)] for _ in range(shape[0])]
+        layer = aug.RandAugment(2, 9, elementwise=True)
+        ref = A.rand_augment_elementwise(x, 2, 9, dec)
+        plan = layer.items_plan(shape, dec)
+        _eq(K.aug_fused_items(_dev(x), plan), ref, "per-image chains, uint8")
+        rows = K.aug_fused_items(_dev(x), plan, patch=16)
+        assert torch.equal(rows, K.normalize_patchify(_dev(ref), 16, "tf")), trial
+    cfg = ViTConfig(patch_size=16, patch_dim=128, n_encoder_layers=1, n_heads=2, ff_dim=128, image_size=(64, 64), classes=10, dropout_rate=0.0)
+    eng = ViTEngine(cfg, 4, training=False, seed=0)
+    eng.load_keras_weights(init_keras_weights(cfg, seed=1))
+    xi = _dev(_img((4, 64, 64, 3), 9))
+    layer = aug.AutoAugment(elementwise=True)
+    dec = [{"policy": int(g.integers(0, 25)), "apply": (bool(g.uniform() < 0.5), bool(g.uniform() < 0.5)), "negate": (bool(g.uniform() < 0.5), bool(g.uniform() < 0.5))}
+           for _ in range(4)]
+    a = eng.forward(layer(xi, training=True, decision=dec), training=False).clone()
+    b = eng.forward(xi, training=False, augment=layer.items_plan(xi.shape, dec)).clone()
+    assert torch.equal(a, b)

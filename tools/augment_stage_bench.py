@@ -2,7 +2,8 @@
 ways on a [B,224,224,3] uint8 batch, over all 16 x 16 ordered op pairs (the scheme draws both slots uniformly):
   fused        chb_aug_fused(patch=16): the chain evaluated inside the patchify pass (+ a histogram pass per table op)
   op-by-op     one launch per op, then chb_normalize_patchify_bf16
-  elementwise  per-image decisions: chb_aug_dispatch per slot, then chb_normalize_patchify_bf16
+  elementwise  per-image decisions: every image's chain in one launch (chb_aug_fused_items); and the r02 route: chb_aug_dispatch per
+               slot, then chb_normalize_patchify_bf16
 Algorithmic bytes of the stage = uint8 batch read once + bf16 patch rows written once = 3 * B*H*W*3, whatever the chain.
 Every configuration is replayed from a HIP graph (the kernels are shorter than a Python layer call).
   CHB_STAGE_FUSED_ONLY=1: time the fused path alone and print its table (A/B builds through CHB_AB_LIB: tools/ab_build.sh)."""
@@ -91,7 +92,7 @@ ws = torch.empty(B * 768, dtype=torch.int32, device="cuda")
 bufs = [torch.empty_like(x), torch.empty_like(x)]
 
 
-def elementwise_stage():
+def elementwise_stage_r02():          # rounds 1-2: one dispatch launch per slot (+ statistics), then the patchify pass
     src = x
     for s_ in range(2):
         _lib.call("chb_aug_dispatch", _lib.ptr(src), _lib.ptr(bufs[s_]), B, H, W, _lib.ptr(items_dev[s_]), n_stats[s_], _lib.ptr(ws), K._s())
@@ -99,6 +100,16 @@ def elementwise_stage():
     K.normalize_patchify(src, 16, "tf", out=patches)
 
 
+items_plan = K.AugItemsPlan(items)
+items_plan.resident(x.device)
+torch.cuda.synchronize()
+
+
+def elementwise_stage():              # round 3: every image's chain inside ONE final launch (chb_aug_fused_items)
+    K.aug_fused_items(x, items_plan, patch=16, out=patches)
+
+
+t_elem_r02 = timed(elementwise_stage_r02)
 t_elem = timed(elementwise_stage)
 t_patch = timed(lambda: K.normalize_patchify(x, 16, "tf", out=patches))
 
@@ -106,10 +117,10 @@ fused = np.array([v[0] for v in rows.values()])
 ops = np.array([v[1] for v in rows.values()])
 gbps = lambda us: stage_bytes / us / 1e3     # noqa: E731
 print("stage = RandAugment(2,9) chain -> normalise('tf') -> bf16 patch rows, batch [%d,%d,%d,3]; algorithmic bytes %.1f MB" % (B, H, W, stage_bytes / 1e6))
-print("%-28s %10s %12s %10s" % ("", "us", "alg. GB/s", "of 8 TB/s"))
+print("%-32s %10s %12s %10s" % ("", "us", "alg. GB/s", "of 8 TB/s"))
 for label, us in (("normalise + patchify alone", t_patch), ("fused, mean of 256 pairs", fused.mean()), ("op-by-op, mean of 256 pairs", ops.mean()),
-                  ("elementwise (dispatch x2)", t_elem)):
-    print("%-28s %10.1f %12.1f %9.1f%%" % (label, us, gbps(us), 100 * gbps(us) / 8000))
+                  ("elementwise, per-image chains", t_elem), ("elementwise, dispatch x2 (r02)", t_elem_r02)):
+    print("%-32s %10.1f %12.1f %9.1f%%" % (label, us, gbps(us), 100 * gbps(us) / 8000))
 print("fused: min %.1f us (%s), max %.1f us (%s)" % (fused.min(), list(rows)[int(fused.argmin())], fused.max(), list(rows)[int(fused.argmax())]))
 print("op-by-op: min %.1f us (%s), max %.1f us (%s)" % (ops.min(), list(rows)[int(ops.argmin())], ops.max(), list(rows)[int(ops.argmax())]))
 slow = sorted(rows.items(), key=lambda kv: kv[1][0] / kv[1][1], reverse=True)[:8]
@@ -122,5 +133,5 @@ for title, col in (("fused stage, us (row = first op, column = second op)", 0), 
     for a in names:
         print("%-13s" % a + "".join("%7.0f" % rows[a + ">" + b][col] for b in names))
 print(json.dumps({"batch": B, "size": H, "stage_bytes": stage_bytes, "patchify_us": t_patch, "fused_mean_us": float(fused.mean()),
-                  "op_by_op_mean_us": float(ops.mean()), "elementwise_us": t_elem,
+                  "op_by_op_mean_us": float(ops.mean()), "elementwise_us": t_elem, "elementwise_dispatch_us": t_elem_r02,
                   "pairs": {k: [round(v[0], 1), round(v[1], 1)] for k, v in rows.items()}}))
