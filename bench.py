@@ -451,7 +451,12 @@ def main():
                                   "(overlap_wgrad); see mfma_all_gemms; the default (CHB_OVERLAP_WGRAD unset) runs one stream")
                          if getattr(eng, "overlap_wgrad", False) else "one stream: launches do not overlap",
                          "families": {k: {"total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 1), "launches": v["launches"],
-                                          "frac": round(v["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)} for k, v in fams.items()}},
+                                          "frac": round(v["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)} for k, v in fams.items()},
+                         # what a probe that does nothing else measured on this chip (not `peak`: context for `frac`, DESIGN section 4
+                         # "Round 3" point 5): the MFMA stream alone on real operand bits, and the K-loop of a 256x256 tile with its
+                         # operands streaming in (every placement of the LDS-DMA pieces tried)
+                         "measured_ceilings_tflops": {"mfma_stream_only": 2060.0, "kloop_256x256_tile": 1600.0, "kloop_plus_k768_tile_stores": 1300.0,
+                                                      "source": "profiles/r03_mfma_power_probe.txt (tools/probe/mfma_ta_probe.hip)"}},
             # all GEMM launches together: their FLOPs over the wall time in which at least one of them ran.  The engine issues a
             # block's weight-gradient GEMMs on a second stream beside the dgrad chain (they fill launch tails, launch gaps and
             # the bandwidth-bound kernels' idle MFMA pipes) when CHB_OVERLAP_WGRAD=1; a launch's own duration - what `roofline` prices, as
