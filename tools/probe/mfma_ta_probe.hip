@@ -231,6 +231,165 @@ static void roles(const char* name, unsigned mm, unsigned sm, unsigned pm, int n
     fflush(stdout);
 }
 
+
+// ---- third probe: a complete K-loop for ONE wave per SIMD (4 waves x 128x128 outputs = 256 accumulator registers each), written the
+// way a production kernel would be: 32-deep K-steps in a ring of FOUR 32 KiB stages (the buffer of step j is free at the barrier in
+// front of step j - its fragments are in registers by then - and takes step j + 4: three steps, ~2 us, to land), ONE barrier per step,
+// the fragments of step j + 1 read (inline asm, counted waits) under the 64 MFMAs of step j, one LDS-DMA piece per 8 MFMAs.  Stage
+// tiles are [128 rows][32 k] with 64-byte rows, chunk c of row r at position c ^ ((r >> 1) & 3): conflict-free for the fragment reads.
+// STORES: the 128 KiB of a tile's bf16 output in a burst behind its last step.
+template <int OFF>
+__device__ __forceinline__ void ds_read128(bf16x8_t& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+#define FRAG8(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+
+template <bool STORES, int ABL = 0>      // ABL (timing only, wrong data): 1 = no barrier, 2 = no vmcnt wait, 3 = neither, 4 = no fragment reads
+__global__ void __launch_bounds__(256) kloop4_kernel(const char* __restrict__ A, const char* __restrict__ B, char* __restrict__ C, int tiles, int ksteps,
+                                                     float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];     // 4 stages x 32 KiB: [A rows 0-127 | A rows 128-255 | B 0-127 | B 128-255] x 8 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+    float4_t acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[2][8], fb[2][8];
+    // fragment t of a tile: + 1 KiB t; lane base inside a tile: row i, chunk g swizzled
+    const uint32_t lane_off = (uint32_t)(i * 64 + ((g ^ ((i >> 1) & 3)) << 4));      // (tools/probe/lds_read_probe.hip: the swizzle by (r >> 2) conflicts two-way)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(lds);
+    const uint32_t a_adr = lds0 + wm * 8192 + lane_off, b_adr = lds0 + (2 + wn) * 8192 + lane_off;
+    // staging: piece e (0..31) of a step = tile e >> 3 of the stage, rows 16 (e & 7) .. +15; a wave issues pieces wave, wave + 4, ...
+    const int prow = lane >> 2, pchunk = (lane & 3) ^ ((prow >> 1) & 3);
+    const uint64_t lane_src = (uint64_t)(prow * LD + pchunk * 16) + (uint64_t)wave * 16 * LD;      // piece q of a wave: rows 64 (q & 3) + 16 wave ..
+    uint4 carried = make_uint4(lane, wave, 3, 4);
+    int j = 0;                                      // running k32-step index (ring position j & 3)
+    const int total = tiles * ksteps;
+    // staging stream (three steps ahead of the MFMAs): wave-uniform byte pointers to the current K-step of the A / B panels, moved by
+    // 64 bytes per step and recomputed when the stream enters a new tile
+    int st_step = 0, st_ks = 0, st_t = 0;
+    const char* pa = nullptr;
+    const char* pb = nullptr;
+    auto stream_set = [&]() {
+        const int64_t row0 = ((int64_t)((st_t * gridDim.x + blockIdx.x) / 3) * 256) % (M_ROWS - 256);
+        pa = A + row0 * LD;
+        pb = B + (int64_t)((blockIdx.x % 3) * 256) * LD;
+    };
+    auto stream_next = [&]() {
+        if (st_step + 1 >= total) return;           // (the tail re-loads the last step)
+        ++st_step;
+        if (++st_ks == ksteps) { st_ks = 0; ++st_t; stream_set(); }
+        else if ((st_ks % (LD / 64)) == 0) { pa -= LD - 64; pb -= LD - 64; }     // (K longer than the probe's panels: wrap inside the row)
+        else { pa += 64; pb += 64; }
+    };
+    // piece q (0..7) of this wave in the stream's step: q < 4 from the A panel, else B; tile q >> 1 ... rows 64 (q & 3) + 16 wave .. + 15
+    // of the 256-row panel = LDS tile (q & 3) >> 1 of the operand, KiB slot 4 (q & 3) + wave of the stage half.  Past the last step the
+    // stream keeps loading its last valid step (nobody reads it): no branch in the loop.
+    auto piece = [&](int q) {
+        const char* base = (q < 4 ? pa : pb) + (int64_t)((q & 3) * 64) * LD;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + lane_src), LDS_PTR(lds + (st_step & 3) * 32768 + (q < 4 ? 0 : 16384) + ((q & 3) * 4 + wave) * 1024), 16, 0, 0);
+    };
+    stream_set();
+    // prologue: steps 0, 1, 2 in flight, step 0 landed; fragments of step 0 read
+    for (int st = 0; st < 3; ++st) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) piece(q);
+        stream_next();
+    }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#define READ_SET(SET, STAGE)                                                                                                   \
+    {                                                                                                                          \
+        const uint32_t aa = a_adr + (STAGE) * 32768, bb = b_adr + (STAGE) * 32768;                                             \
+        ds_read128<0>(fa[SET][0], aa); ds_read128<1024>(fa[SET][1], aa); ds_read128<2048>(fa[SET][2], aa); ds_read128<3072>(fa[SET][3], aa);   \
+        ds_read128<4096>(fa[SET][4], aa); ds_read128<5120>(fa[SET][5], aa); ds_read128<6144>(fa[SET][6], aa); ds_read128<7168>(fa[SET][7], aa); \
+        ds_read128<0>(fb[SET][0], bb); ds_read128<1024>(fb[SET][1], bb); ds_read128<2048>(fb[SET][2], bb); ds_read128<3072>(fb[SET][3], bb);   \
+        ds_read128<4096>(fb[SET][4], bb); ds_read128<5120>(fb[SET][5], bb); ds_read128<6144>(fb[SET][6], bb); ds_read128<7168>(fb[SET][7], bb); \
+    }
+    READ_SET(0, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" : FRAG8(fa[0]), FRAG8(fb[0]));
+#define RD(SET, WHICH, T, BASE) { if (ABL != 4) ds_read128<(T) * 1024>(WHICH[SET][T], BASE); }
+#define STEP(CUR, NXT)                                                                                                         \
+    {                                                                                                                          \
+        const uint32_t aa = a_adr + ((j + 1) & 3) * 32768, bb = b_adr + ((j + 1) & 3) * 32768;                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        _Pragma("unroll") for (int a = 0; a < 8; ++a) {                                                                        \
+            _Pragma("unroll") for (int b = 0; b < 8; ++b) {                                                                    \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][b], fa[CUR][a], acc[a][b], 0, 0, 0);               \
+                __builtin_amdgcn_sched_barrier(0);                                                                             \
+                /* every instruction that is not an MFMA sits alone behind one: a fragment read of step j + 1 behind MFMAs 0, 2, 4, 6 */ \
+                /* of a group's first half ... (16 per step), the group's piece behind MFMA 5 */                              \
+                if (b == 0) { if (a == 0) RD(NXT, fa, 0, aa) else if (a == 1) RD(NXT, fa, 2, aa) else if (a == 2) RD(NXT, fa, 4, aa) else if (a == 3) RD(NXT, fa, 6, aa) \
+                              else if (a == 4) RD(NXT, fb, 0, bb) else if (a == 5) RD(NXT, fb, 2, bb) else if (a == 6) RD(NXT, fb, 4, bb) else RD(NXT, fb, 6, bb) } \
+                if (b == 2) { if (a == 0) RD(NXT, fa, 1, aa) else if (a == 1) RD(NXT, fa, 3, aa) else if (a == 2) RD(NXT, fa, 5, aa) else if (a == 3) RD(NXT, fa, 7, aa) \
+                              else if (a == 4) RD(NXT, fb, 1, bb) else if (a == 5) RD(NXT, fb, 3, bb) else if (a == 6) RD(NXT, fb, 5, bb) else RD(NXT, fb, 7, bb) } \
+                if (b == 5) piece(a);                                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                             \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        stream_next();                                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" : FRAG8(fa[NXT]), FRAG8(fb[NXT]));                                                 \
+        if (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       /* step j + 2 has landed: the 16 pieces of steps j + 3, j + 4 stay in flight */ \
+        if (!(ABL & 1)) __builtin_amdgcn_s_barrier();                                                                          \
+        ++j;                                                                                                                   \
+    }
+    for (int t = 0; t < tiles; ++t) {
+        for (int ks = 0; ks < ksteps; ks += 2) {
+            STEP(0, 1)
+            STEP(1, 0)
+        }
+        if (STORES) {
+            char* pc = C + ((int64_t)((t * gridDim.x + blockIdx.x) % 1000) * 256 * 256 * 2);
+#pragma unroll
+            for (int e = 0; e < 32; ++e) *reinterpret_cast<uint4*>(pc + (int64_t)(e * 4 + wave) * 1024 + lane * 16) = carried;
+            carried.x += 1;
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (sum == 12345.678f) sink[tid] = sum;
+    if (tid == 0) {
+        reinterpret_cast<unsigned long long*>(sink + 1024)[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - st0;
+        reinterpret_cast<unsigned long long*>(sink + 1024)[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    }
+}
+#undef STEP
+#undef RD
+#undef READ_SET
+
+template <bool STORES, int ABL = 0>
+static void run_kloop4(const char* name, const char* A, const char* B, char* C, float* sink, int tiles, int ksteps) {
+    auto k = kloop4_kernel<STORES, ABL>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k, dim3(256), dim3(256), 131072, 0, A, B, C, tiles, ksteps, sink);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double flop = 256.0 * tiles * ksteps * 256.0 * 256.0 * 32.0 * 2.0;
+    static unsigned long long hc[512];
+    CHECK(hipMemcpy(hc, sink + 1024, sizeof(hc), hipMemcpyDeviceToHost));
+    double clk = 0, ticks = 0;
+    for (int b = 0; b < 256; ++b) { clk += (double)hc[2 * b]; ticks += (double)hc[2 * b + 1]; }
+    printf("%-58s %8.3f ms  %7.1f TFLOP/s  (%.3f of 2.5 PF)  %.3f GHz  pipe %.3f\n", name, best, flop / best * 1e-9, flop / best * 1e-9 / 2500.0,
+           clk / ticks * 0.1, (double)tiles * ksteps * 1024.0 / (clk / 256.0));
+    fflush(stdout);
+}
+
 template <int WAVES, bool PIECES, int MODE, bool READS, int PMODE = 0, int DEPTH = 1>
 static void run(const char* name, const char* A, const char* B, char* C, const bf16x8_t* fi, float* sink, int tiles) {
     auto k = probe_kernel<WAVES, PIECES, MODE, READS, PMODE, DEPTH>;
@@ -338,6 +497,14 @@ int main(int argc, char** argv) {
     run<8, true, 0, false, 5>("8 waves, all pieces in waves 4-7", A, B, C, fi, sink, tiles);
     run<8, true, 1, false, 4>("8 waves, all pieces in waves 0-3 + store burst", A, B, C, fi, sink, tiles);
     run<8, true, 0, true, 4>("8 waves, all pieces in waves 0-3 + fragment reads", A, B, C, fi, sink, tiles);
+    run_kloop4<false>("4-wave K-loop (ring of 4 x k32, 1 barrier / step), K = 768", A, B, C, sink, tiles, 24);
+    run_kloop4<true>("4-wave K-loop + store burst per tile, K = 768", A, B, C, sink, tiles, 24);
+    run_kloop4<false>("4-wave K-loop, K = 3072", A, B, C, sink, tiles / 4, 96);
+    run_kloop4<false, 1>("4-wave K-loop, K = 3072, no barrier (timing only)", A, B, C, sink, tiles / 4, 96);
+    run_kloop4<false, 2>("4-wave K-loop, K = 3072, no vmcnt wait (timing only)", A, B, C, sink, tiles / 4, 96);
+    run_kloop4<false, 3>("4-wave K-loop, K = 3072, neither (timing only)", A, B, C, sink, tiles / 4, 96);
+    run_kloop4<false, 4>("4-wave K-loop, K = 3072, no fragment reads (timing only)", A, B, C, sink, tiles / 4, 96);
+    run_kloop4<true>("4-wave K-loop + store burst per tile, K = 3072", A, B, C, sink, tiles / 4, 96);
     if (quick) return 0;
     run<8, true, 0, false, 0, 2>("8 waves, + 64 pieces / K-step, two steps in flight", A, B, C, fi, sink, tiles);
     run<4, true, 0, false, 0, 2>("4 waves, + 64 pieces / K-step, two steps in flight", A, B, C, fi, sink, tiles);
