@@ -1304,6 +1304,7 @@ __device__ __forceinline__ bool affine_source(const FusedOp& o, int W, int H, in
 
 template <bool ITEMS = false>
 __device__ __forceinline__ bool cutout_inside(const FusedParams& P, int l, int n, int y, int x) {
+    if (ITEMS && !P.centers[l]) return false;        // per-image records on the device: the host could not check that a centre table came with them
     const int cy = P.centers[l][2 * n], cx = P.centers[l][2 * n + 1], half = fused_op<ITEMS>(P, n, l).i2;
     return (y >= max(0, cy - half)) && (y < min(P.H, cy + half)) && (x >= max(0, cx - half)) && (x < min(P.W, cx + half));
 }

@@ -326,7 +326,7 @@ int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, 
 /* The same stage for the schemes' elementwise=True mode (image_augmentations.py:563-570, augmentation_schemes.py:135: tf.map_fn over
  * batch-1 tensors - every image draws its own ops, signs, cutout centre, and Contrast's constant is its own H*W/256).  items_dev:
  * DEVICE records, one per (level, image), [n_ops][B], laid out as chb_aug_fused's host records.  centers_dev[l]: device int32 [B,2]
- * for the images with a CutOut at level l (NULL if none).  table_levels: bit l set if some image has an AutoContrast / Equalize at
+ * for the images with a CutOut at level l (NULL if none; a CutOut record at a level without a table leaves its image untouched).  table_levels: bit l set if some image has an AutoContrast / Equalize at
  * level l; workspace: chb_aug_fused_workspace_ints(B, H, W, popcount(table_levels)) int32, uninitialised.  One launch for the batch
  * (+ a histogram pass and a table launch per set bit); out as for chb_aug_fused.  Bit-identical to the ops applied image by image. */
 int chb_aug_fused_items(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev,

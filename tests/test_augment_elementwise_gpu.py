@@ -189,3 +189,22 @@ def test_per_image_chains_as_patch_rows_and_through_the_engine():
     a = eng.forward(layer(xi, training=True, decision=dec), training=False).clone()
     b = eng.forward(xi, training=False, augment=layer.items_plan(xi.shape, dec)).clone()
     assert torch.equal(a, b)
+
+
+def test_per_image_cutout_without_a_centre_table_is_left_out():
+    """chb_aug_fused_items cannot see the device records on the host: a CutOut record at a level whose centre table is NULL must not
+    dereference it - the image passes that level untouched."""
+    import ctypes
+    from chambers_amd import _lib
+    from chambers_amd import augmentations as aug
+    from chambers_amd import kernels as K
+    shape = (3, 20, 24, 3)
+    x = _img(shape, 21)
+    dec = [[{"op": 14, "negate": False, "centers": (5, 6)}, {"op": 2, "negate": False, "centers": (1, 1)}] for _ in range(3)]
+    plan = aug.RandAugment(2, 9, elementwise=True).items_plan(shape, dec)
+    xd = _dev(x)
+    dev_items, _centers, tables = plan.resident(xd.device)
+    out = torch.empty_like(xd)
+    cptr = (ctypes.c_void_p * 2)()          # no centre tables at all
+    _lib.call("chb_aug_fused_items", _lib.ptr(xd), _lib.ptr(out), 3, 20, 24, 2, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables, None, 0, K._s())
+    _eq(out, A.invert(x), "CutOut without centres -> Invert alone")
