@@ -61,6 +61,9 @@ PROTOTYPES = {
     "chb_l2_normalize_fwd": [P, P, P, c_int, c_int, P],
     "chb_l2_normalize_bwd": [P, P, P, P, c_int, c_int, P],
     "chb_multi_similarity_loss": [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_int, P],
+    "chb_multi_similarity_loss_matrix": [P, P, P, P, c_int, c_float, c_float, c_float, c_float, c_int, c_int, P],
+    "chb_contrastive_loss": [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_int, P],
+    "chb_ntxent_loss": [P, P, P, P, P, c_int, c_int, c_float, c_int, P],
     "chb_resize": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "chb_resize_ragged": [P, c_int64, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
     "chb_crop_flip": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P],

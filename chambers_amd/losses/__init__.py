@@ -1,2 +1,2 @@
-"""chambers.losses on MI355X: the metric-learning loss the ViT backbones are trained with."""
-from .metric_learning import MultiSimilarityLoss  # noqa: F401
+"""chambers.losses namespace (metric-learning pair losses; reference: chambers/losses/metric_learning.py)."""
+from .metric_learning import ContrastiveLoss, MultiSimilarityLoss, MultiSimilarityLossMatrix, NTXentLoss  # noqa: F401

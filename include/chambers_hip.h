@@ -281,6 +281,22 @@ int chb_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm,
 int chb_multi_similarity_loss(const float* emb, const int32_t* labels, float* loss_rows, float* workspace, float* d_emb,
                               int B, int D, float pos_scale, float neg_scale, float threshold, float miner_margin,
                               int use_miner, int ignore_diag, int ignore_negative_labels, void* stream);
+/* The PairMatrixLoss form (losses/metric_learning.py:112-121, MultiSimilarityLossMatrix :181-235): `sim` fp32 [B,B] IS the similarity
+ * matrix, positive_mask uint8 [B,B] its boolean positive-pair mask (y_true cast to bool); d_sim (NULL or fp32 [B,B]) receives
+ * d(mean loss)/d(sim). */
+int chb_multi_similarity_loss_matrix(const float* sim, const uint8_t* positive_mask, float* loss_rows, float* d_sim, int B, float pos_scale,
+                                     float neg_scale, float threshold, float miner_margin, int use_miner, int ignore_diag, void* stream);
+/* ContrastiveLoss (losses/metric_learning.py:238-287) on embeddings: loss_rows[i] = sum over kept positives of (positive_margin - s)^e / e
+ * + sum over kept negatives of max(0, s - negative_margin)^e / e (tf.pow semantics, e = exponent); pairs, miner, gradient and
+ * workspace as for chb_multi_similarity_loss. */
+int chb_contrastive_loss(const float* emb, const int32_t* labels, float* loss_rows, float* workspace, float* d_emb, int B, int D,
+                         float positive_margin, float negative_margin, float exponent, float miner_margin, int use_miner, int ignore_diag,
+                         int ignore_negative_labels, void* stream);
+/* NTXentLoss (losses/metric_learning.py:290-323): Keras CategoricalCrossentropy of the rows of emb.emb^T / temperature (diagonal set to
+ * -1e9) against the multi-hot rows [label_j == label_i, j != i]; from_logits != 0: -sum y log softmax(z); else the probability form
+ * (rows divided by their sum, clipped to [1e-7, 1 - 1e-7]).  loss_rows fp32 [B] (the Keras value is their mean), d_emb / workspace as above. */
+int chb_ntxent_loss(const float* emb, const int32_t* labels, float* loss_rows, float* workspace, float* d_emb, int B, int D, float temperature,
+                    int from_logits, void* stream);
 
 /* fp32 [R,C] -> bf16 [R,C] and/or bf16 [C,R] for a table of matrices (one launch). desc is a
  * device int64 array [n,4] = {src_offset, dst_offset, R, C} in elements; dst_t gets the

@@ -80,3 +80,75 @@ def test_retrieval_training_loop_through_the_engine():
         eng.adamw_step(learning_rate=1e-3)
         history.append(float(value))
     assert np.isfinite(history).all() and history[0] > 0.1 and min(history[-5:]) < 0.5 * history[0], history[::10]
+
+
+def _pair_data(seed=3, n=80, d=24):
+    g = torch.Generator().manual_seed(seed)
+    emb = metric_ref.l2_normalize(torch.randn(n, d, generator=g))
+    labels = torch.randint(0, 9, (n,), generator=g)
+    labels[2], labels[11] = -1, -1
+    labels[5] = 77
+    return emb, labels
+
+
+@pytest.mark.parametrize("miner,exponent,ignore_diag,ignore_neg", [(None, 2, True, True), (0.1, 2, True, True), (None, 3, False, True), (None, 1, True, False)])
+def test_contrastive_loss_matches_oracle(miner, exponent, ignore_diag, ignore_neg):
+    from chambers_amd.losses import ContrastiveLoss
+    from chambers_amd.miners import MultiSimilarityMiner
+    emb, labels = _pair_data()
+    loss_fn = ContrastiveLoss(exponent=exponent, ignore_diag=ignore_diag, ignore_negative_labels=ignore_neg,
+                              miner=None if miner is None else MultiSimilarityMiner(miner))
+    er = emb.clone().requires_grad_(True)
+    rows_ref = metric_ref.contrastive_loss(labels, er, exponent=exponent, ignore_diag=ignore_diag, ignore_negative_labels=ignore_neg, miner_margin=miner)
+    rows_ref.mean().backward()
+    rows = loss_fn.per_sample(labels, emb.cuda())
+    assert torch.allclose(rows.cpu(), rows_ref.detach(), rtol=2e-4, atol=1e-5), float((rows.cpu() - rows_ref.detach()).abs().max())
+    value, grad = loss_fn.value_and_gradient(labels, emb.cuda())
+    assert abs(float(value) - float(rows_ref.detach().mean())) < 1e-5 * max(1.0, abs(float(rows_ref.detach().mean())))
+    assert rel_l2(grad, er.grad) < 1e-4, rel_l2(grad, er.grad)
+    cfg = loss_fn.get_config()
+    assert cfg["positive_margin"] == 1.0 and cfg["negative_margin"] == 0.3 and cfg["exponent"] == exponent and cfg["name"] == "contrastive_loss"
+
+
+@pytest.mark.parametrize("temperature,from_logits", [(1.0, True), (0.2, True), (1.0, False), (0.5, False)])
+def test_ntxent_loss_matches_oracle(temperature, from_logits):
+    from chambers_amd.losses import NTXentLoss
+    emb, labels = _pair_data(seed=4)
+    if not from_logits:
+        emb = emb * 3.0                      # (the probability form only sees the clip unless rows are far from normalised)
+    loss_fn = NTXentLoss(temperature=temperature, from_logits=from_logits)
+    er = emb.clone().requires_grad_(True)
+    rows_ref = metric_ref.ntxent_loss(labels, er, temperature=temperature, from_logits=from_logits)
+    rows_ref.mean().backward()
+    rows = loss_fn.per_sample(labels, emb.cuda())
+    assert torch.allclose(rows.cpu(), rows_ref.detach(), rtol=2e-4, atol=1e-4), float((rows.cpu() - rows_ref.detach()).abs().max())
+    value, grad = loss_fn.value_and_gradient(labels, emb.cuda())
+    assert abs(float(value) - float(rows_ref.detach().mean())) < 1e-4 * max(1.0, abs(float(rows_ref.detach().mean())))
+    ref_g = er.grad
+    if float(ref_g.norm()) > 0:
+        assert rel_l2(grad, ref_g) < 2e-4, rel_l2(grad, ref_g)
+    else:
+        assert float(grad.abs().max()) == 0.0
+    assert loss_fn.get_config() == {"name": None, "temperature": temperature, "from_logits": from_logits}
+
+
+@pytest.mark.parametrize("miner,ignore_diag", [(0.1, True), (None, True), (0.1, False)])
+def test_multi_similarity_loss_matrix_matches_oracle(miner, ignore_diag):
+    from chambers_amd.losses import MultiSimilarityLossMatrix
+    from chambers_amd.miners import MultiSimilarityMiner
+    emb, labels = _pair_data(seed=5, n=64)
+    sim = emb @ emb.t()
+    mask = (labels.reshape(-1, 1) == labels.reshape(1, -1))
+    loss_fn = MultiSimilarityLossMatrix(ignore_diag=ignore_diag, miner=None if miner is None else MultiSimilarityMiner(miner))
+    sr = sim.clone().requires_grad_(True)
+    rows_ref = metric_ref.multi_similarity_loss_matrix(mask, sr, ignore_diag=ignore_diag, miner_margin=miner)
+    rows_ref.mean().backward()
+    rows = loss_fn.per_sample(mask.cuda(), sim.cuda())
+    assert torch.allclose(rows.cpu(), rows_ref.detach(), rtol=2e-4, atol=1e-5), float((rows.cpu() - rows_ref.detach()).abs().max())
+    value, grad = loss_fn.value_and_gradient(mask.to(torch.int32).cuda(), sim.cuda())
+    assert rel_l2(grad, sr.grad) < 1e-4, rel_l2(grad, sr.grad)
+    # on the same pairs the matrix form and the embedding form agree
+    from chambers_amd.losses import MultiSimilarityLoss
+    rows_e = MultiSimilarityLoss(ignore_diag=ignore_diag, ignore_negative_labels=False,
+                                 miner=None if miner is None else MultiSimilarityMiner(miner)).per_sample(labels, emb.cuda())
+    assert torch.allclose(rows.cpu(), rows_e.cpu(), rtol=1e-4, atol=1e-5)

@@ -271,8 +271,12 @@ def test_schedule_activation_miner_loss_signatures():
     # the constants of the exact and the tanh form (activations.py:30-56)
     assert g["float_literals"] == [0.044715, 0.5, 0.7978845608028654, 1.0, 1.4142135623730951]
     _check_signature(miners.MultiSimilarityMiner, REF["classes"]["miners.py"]["MultiSimilarityMiner"]["init"], "MultiSimilarityMiner")
-    _check_signature(metric_learning.MultiSimilarityLoss, REF["classes"]["losses/metric_learning.py"]["MultiSimilarityLoss"]["init"],
-                     "MultiSimilarityLoss")
+    for cls in ("MultiSimilarityLoss", "MultiSimilarityLossMatrix", "ContrastiveLoss", "NTXentLoss"):
+        _check_signature(getattr(metric_learning, cls), REF["classes"]["losses/metric_learning.py"][cls]["init"], cls)
+    # the default miner of the two multi-similarity losses is the reference's expression
+    assert REF["classes"]["losses/metric_learning.py"]["MultiSimilarityLossMatrix"]["init"]["defaults"]["miner"] == {"expr": "_MSMiner(margin=0.1)"}
+    assert metric_learning.MultiSimilarityLossMatrix().miner.margin == 0.1 and metric_learning.MultiSimilarityLoss().miner.margin == 0.1
+    assert metric_learning.ContrastiveLoss().miner is None
 
 
 def test_oracle_layer_constants_follow_the_fixture():
