@@ -1768,6 +1768,96 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
     }
 }
 
+// ---- FUSED_LOCAL chains, final pass: every level reads only its own pixel, so the launch is the normalise + patchify pass with the
+// chain applied to the quad between load and store - and it takes that kernel's shape (r03): 8 rows per wave, TWO quads per trip with
+// both loads issued before either chain runs.  grid = (groups of 32 rows, B).
+template <int L>
+struct FusedApply {
+    static __device__ __forceinline__ void on(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
+        FusedApply<L - 1>::on(P, C, y, x0, b);
+        const FusedOp& o = P.ops[L];
+        const int op = o.op;
+        if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
+            const uint8_t* lut = C.lut + L * 768;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
+        } else if (op == CHB_AUG_CUTOUT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool inside = cutout_inside(P, L, C.n, y, x0 + i);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+            }
+        } else {
+            quad_pointwise(op, b, o);
+        }
+    }
+};
+template <>
+struct FusedApply<-1> {
+    static __device__ __forceinline__ void on(const FusedParams&, const FusedCtx&, int, int, uint8_t (&)[12]) {}
+};
+
+template <int NLEV, bool PATCH>
+__global__ void __launch_bounds__(256) fused_local_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw,
+                                                          int fast) {
+    constexpr int ROWS = 8;
+    __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
+    const int n = blockIdx.y;
+    fused_stage_luts(P, n, lutS);
+    const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wq = PATCH ? (gw * patch) >> 2 : (P.W + 3) >> 2;
+    const int hh = PATCH ? gh * patch : P.H;
+    const int row0 = blockIdx.x * (4 * ROWS) + wave * ROWS;
+    const int K = patch * patch * 3;
+    if (row0 >= hh) return;
+    const int nrows = min(ROWS, hh - row0);
+    const int ps = (PATCH && (patch & (patch - 1)) == 0) ? (31 - __builtin_clz(patch)) : -1;     // uniform
+    auto emit = [&](int y, int x0, uint8_t (&b)[12]) {
+        if (PATCH) {
+            float f[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) f[i] = norm1<1>(b[i], i % 3, NormConst{});
+            int py, px, ry, rx;
+            if (ps >= 0) { py = y >> ps; px = x0 >> ps; ry = y & (patch - 1); rx = x0 & (patch - 1); }
+            else { py = y / patch; px = x0 / patch; ry = y - py * patch; rx = x0 - px * patch; }
+            const int64_t row = ((int64_t)n * gh + py) * gw + px;
+            const int col = (ry * patch + rx) * 3;
+            uint2* d = reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + row * K + col);     // 24 bytes, 8-byte aligned
+            d[0] = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+            d[1] = make_uint2(pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+            d[2] = make_uint2(pack_bf16x2(f[8], f[9]), pack_bf16x2(f[10], f[11]));
+        } else {
+            uint8_t* orow = reinterpret_cast<uint8_t*>(out) + ((int64_t)n * P.H + y) * P.W * 3;
+            if (C.fast) store_quad<true>(orow, x0, P.W, b);
+            else store_quad<false>(orow, x0, P.W, b);
+        }
+    };
+    int k = 0, xq = lane;
+    while (xq >= wq) { xq -= wq; ++k; }
+    const int adv_k = 64 / wq, adv_x = 64 - adv_k * wq;
+    while (k < nrows) {
+        int k2 = k + adv_k, xq2 = xq + adv_x;
+        if (xq2 >= wq) { xq2 -= wq; ++k2; }
+        const bool two = k2 < nrows;
+        uint8_t ba[12], bb[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) bb[i] = 0;
+        FusedQuad<-1, FUSED_LOCAL>::at(P, C, row0 + k, xq * 4, ba);
+        if (two) FusedQuad<-1, FUSED_LOCAL>::at(P, C, row0 + k2, xq2 * 4, bb);
+        FusedApply<NLEV - 1>::on(P, C, row0 + k, xq * 4, ba);
+        emit(row0 + k, xq * 4, ba);
+        if (two) {
+            FusedApply<NLEV - 1>::on(P, C, row0 + k2, xq2 * 4, bb);
+            emit(row0 + k2, xq2 * 4, bb);
+        }
+        k = k2 + adv_k;
+        xq = xq2 + adv_x;
+        if (xq >= wq) { xq -= wq; ++k; }
+    }
+}
+
 // ---- a Sharpness with the chain around it in ONE launch (r03; before: the levels below into a uint8 scratch image, the stand-alone
 // Sharpness into another, then normalise + patchify - three launches and two round trips).  A wave walks down 8 output rows, a lane
 // owns the same quad in all of them; each input row is a quad of level S-1, evaluated once where it is needed (BMODE: the launch
@@ -2236,9 +2326,10 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
         return n_tables;
     }
     const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);
+    const dim3 lgrid(((patch ? gh * patch : H) + 31) / 32, B);      // fused_local_kernel: 8 rows per wave
 #define CHB_FUSED_FINAL2(NL, PT)                                                                                                            \
     do {                                                                                                                                    \
-        if (local) hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_LOCAL>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);     \
+        if (local) hipLaunchKernelGGL((fused_local_kernel<NL, PT>), lgrid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);                \
         else if (rows) hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_ROWS>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);  \
         else hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_GENERAL>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);         \
     } while (0)
