@@ -1754,9 +1754,10 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
             else { py = y / patch; px = x0 / patch; ry = y - py * patch; rx = x0 - px * patch; }
             const int64_t row = ((int64_t)n * gh + py) * gw + px;
             const int col = (ry * patch + rx) * 3;
-            uint32_t* d = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(out) + row * K + col);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+            uint2* d = reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + row * K + col);     // 24 bytes, 8-byte aligned (col * 2 is a multiple of 24)
+            d[0] = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+            d[1] = make_uint2(pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+            d[2] = make_uint2(pack_bf16x2(f[8], f[9]), pack_bf16x2(f[10], f[11]));
         } else {
             uint8_t* orow = reinterpret_cast<uint8_t*>(out) + ((int64_t)n * P.H + y) * P.W * 3;
             if (C.fast) store_quad<true>(orow, x0, P.W, b);
@@ -1976,9 +1977,10 @@ __global__ void __launch_bounds__(256) fused_sharp_kernel(const uint8_t* __restr
                     else { py = y / patch; px = x0 / patch; ry = y - py * patch; rx = x0 - px * patch; }
                     const int64_t row = ((int64_t)n * gh + py) * gw + px;
                     const int col = (ry * patch + rx) * 3;
-                    uint32_t* d = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(out) + row * K + col);
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) d[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+                    uint2* d = reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + row * K + col);     // 24 bytes, 8-byte aligned
+                    d[0] = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+                    d[1] = make_uint2(pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+                    d[2] = make_uint2(pack_bf16x2(f[8], f[9]), pack_bf16x2(f[10], f[11]));
                 } else {
                     uint8_t* orow = reinterpret_cast<uint8_t*>(out) + ((int64_t)n * H + y) * W * 3;
                     if (C.fast) store_quad<true>(orow, x0, W, b);
