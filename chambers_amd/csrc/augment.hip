@@ -1717,7 +1717,7 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
     for (int i = threadIdx.x; i < 768; i += blockDim.x) mine[i] = h[(i & ~255) + hist_slot(i & 255)];
 }
 
-// final pass: grid = (row groups of 16, B); wave = 4 consecutive rows, lane = 4-pixel quad.
+// final pass: grid = (row groups of 4 RW, B); wave = RW consecutive rows, lane = 4-pixel quad.
 // PATCH: "tf" normalisation + bf16 patch rows (patch % 4 == 0: a quad never straddles patches), else uint8 NHWC
 template <int NLEV, bool PATCH, int MODE>
 __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw,
@@ -1729,11 +1729,14 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = PATCH ? (gw * patch) >> 2 : (P.W + 3) >> 2;
     const int hh = PATCH ? gh * patch : P.H;
-    const int row0 = blockIdx.x * 16 + wave * 4;
+    // rows per wave: 8 where a quad is cheap (FUSED_ROWS, like fused_local_kernel: with 4 the per-workgroup set-up showed), 4 under the
+    // per-pixel gathers of the general modes (8 measured 10 % slower there)
+    constexpr int RW = (MODE == FUSED_ROWS) ? 8 : 4;
+    const int row0 = blockIdx.x * (4 * RW) + wave * RW;
     const int K = patch * patch * 3;
     if (row0 >= hh) return;
-    const int nrows = min(4, hh - row0);
-    // The wave's 4 rows x wq quads as one index space: all 64 lanes busy whatever the row length.  No integer division in the loop
+    const int nrows = min(RW, hh - row0);
+    // The wave's RW rows x wq quads as one index space: all 64 lanes busy whatever the row length.  No integer division in the loop
     // (r03: five of them per quad - idx / wq and the patch coordinates - cost more vector instructions than a pixel-local chain
     // itself): (row, quad) advance by 64 quads per trip, and a power-of-two patch edge (16, 32: every ViT of the zoo) turns the patch
     // coordinates into shifts and masks; other edges keep the division.
@@ -2327,12 +2330,12 @@ static int fused_segment(const uint8_t* src, void* dst, int B, int H, int W, int
 #undef CHB_FUSED_SHARP2
         return n_tables;
     }
-    const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);
-    const dim3 lgrid(((patch ? gh * patch : H) + 31) / 32, B);      // fused_local_kernel: 8 rows per wave
+    const dim3 lgrid(((patch ? gh * patch : H) + 31) / 32, B);      // fused_local_kernel, FUSED_ROWS: 8 rows per wave
+    const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);       // general modes: 4
 #define CHB_FUSED_FINAL2(NL, PT)                                                                                                            \
     do {                                                                                                                                    \
         if (local) hipLaunchKernelGGL((fused_local_kernel<NL, PT>), lgrid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);                \
-        else if (rows) hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_ROWS>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);  \
+        else if (rows) hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_ROWS>), lgrid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast); \
         else hipLaunchKernelGGL((fused_final_kernel<NL, PT, FUSED_GENERAL>), grid, dim3(256), 0, s, src, dst, P, patch, gh, gw, fast);         \
     } while (0)
 #define CHB_FUSED_FINAL(NL)                \
