@@ -1302,6 +1302,15 @@ __device__ __forceinline__ bool affine_source(const FusedOp& o, int W, int H, in
     return ok;
 }
 
+// The constant arm of a per-byte select (CutOut's value, a warp's fill), held in a vector register.  With the op records
+// loop-invariant - in scalar registers - hipcc 7.2 emitted wrong byte selects for CutOut -> Equalize chains
+// (profiles/r03_augment_stage.txt note (h)); behind this opaque move the same build is bit-exact.  One v_mov per level.
+__device__ __forceinline__ uint32_t vgpr_byte(int v) {
+    uint32_t r = (uint32_t)v & 0xffu;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 template <bool ITEMS = false>
 __device__ __forceinline__ bool cutout_inside(const FusedParams& P, int l, int n, int y, int x) {
     if (ITEMS && !P.centers[l]) return false;        // per-image records on the device: the host could not check that a centre table came with them
@@ -1345,10 +1354,10 @@ struct FusedEval {
         uint32_t konst = 0;
         if (op == CHB_AUG_AFFINE) {
             keep = affine_source(o, P.W, P.H, x, y, sx, sy);
-            konst = ((uint32_t)(o.i0 & 0xff)) * 0x010101u;
+            konst = vgpr_byte(o.i0) * 0x010101u;
         } else if (op == CHB_AUG_CUTOUT) {
             keep = !cutout_inside<ITEMS>(P, L, C.n, y, x);
-            konst = ((uint32_t)(o.i3 & 0xff)) * 0x010101u;
+            konst = vgpr_byte(o.i3) * 0x010101u;
         }
         const uint32_t v = FusedEval<L - 1, ITEMS>::at(P, C, sy, sx);
         if (!keep) return konst;
@@ -1389,7 +1398,7 @@ struct FusedGather {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ok[i] = affine_source(o, P.W, P.H, xs[i], ys[i], x2[i], y2[i]);
             FusedGather<L - 1, ITEMS>::at(P, C, y2, x2, b);
-            const uint8_t fill = (uint8_t)(o.i0 & 0xff);
+            const uint8_t fill = (uint8_t)vgpr_byte(o.i0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1402,11 +1411,12 @@ struct FusedGather {
 #pragma unroll
             for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
         } else if (op == CHB_AUG_CUTOUT) {
+const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool inside = cutout_inside<ITEMS>(P, L, C.n, ys[i], xs[i]);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? cutv : b[3 * i + c];
             }
         } else {
             quad_pointwise(op, b, o);
@@ -1450,7 +1460,7 @@ struct FusedQuad {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ok[i] = affine_source(o, P.W, P.H, x0 + i, y, xs[i], ys[i]);
             FusedGather<L - 1, ITEMS>::at(P, C, ys, xs, b);
-            const uint8_t fill = (uint8_t)(o.i0 & 0xff);
+            const uint8_t fill = (uint8_t)vgpr_byte(o.i0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1509,11 +1519,12 @@ struct FusedQuad {
 #pragma unroll
             for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
         } else if (op == CHB_AUG_CUTOUT) {
+const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool inside = cutout_inside<ITEMS>(P, L, C.n, y, x0 + i);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? cutv : b[3 * i + c];
             }
         } else {
             quad_pointwise(op, b, o);
@@ -1540,7 +1551,7 @@ struct FusedRow {
             const float fy = (float)y;
             const float ry = roundf((o.f[3] * 0.0f + o.f[4] * fy) + o.f[5]);
             const bool rowok = (ry >= 0.0f) && (ry < (float)P.H);
-            const uint8_t fill = (uint8_t)(o.i0 & 0xff);
+            const uint8_t fill = (uint8_t)vgpr_byte(o.i0);
             int x2[4];
             bool ok[4];
             if (o.pad == 1) {                   // a pure shift on this H x W (affine_row_contiguous): no per-pixel evaluation at all
@@ -1573,11 +1584,12 @@ struct FusedRow {
 #pragma unroll
             for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
         } else if (op == CHB_AUG_CUTOUT) {
+const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool inside = cutout_inside(P, L, C.n, y, xs[i]);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? cutv : b[3 * i + c];
             }
         } else {
             quad_pointwise(op, b, o);
@@ -1786,11 +1798,12 @@ struct FusedApply {
 #pragma unroll
             for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
         } else if (op == CHB_AUG_CUTOUT) {
+const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool inside = cutout_inside(P, L, C.n, y, x0 + i);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+                for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? cutv : b[3 * i + c];
             }
         } else {
             quad_pointwise(op, b, o);
@@ -1961,11 +1974,12 @@ __global__ void __launch_bounds__(256) fused_sharp_kernel(const uint8_t* __restr
 #pragma unroll
                         for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
                     } else if (o.op == CHB_AUG_CUTOUT) {
+const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const bool inside = cutout_inside(P, l, C.n, y, x0 + i);
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? (uint8_t)o.i3 : b[3 * i + c];
+                            for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? cutv : b[3 * i + c];
                         }
                     } else {
                         quad_pointwise(o.op, b, o);
