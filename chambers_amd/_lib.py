@@ -36,6 +36,8 @@ PROTOTYPES = {
     "chb_aug_fused": [P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P],
     "chb_aug_fused_workspace_ints": [c_int, c_int, c_int, c_int],
     "chb_aug_fused_items": [P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, P],
+    "chb_aug_items_sort": [P, c_int, c_int, c_int, c_int, P, P],
+    "chb_aug_fused_items_sorted": [P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, P, P, P],
     "chb_normalize_u8": [P, P, c_int64, c_int, c_int, P],
     "chb_normalize_f32": [P, P, c_int64, c_int, c_int, P],
     "chb_normalize_patchify_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, P],

@@ -1213,10 +1213,15 @@ struct FusedParams {
     const int32_t* centers[CHB_FUSED_MAX_OPS];    // level's [B][2] cutout centres (cy, cx), else NULL
     int32_t B, H, W;
     const FusedOp* items;                          // NULL, or per-image records [n][B] (elementwise schemes): they replace ops[]
+    const int32_t* order;                          // NULL, or image indices sorted by launch group: blockIdx.y = position n0 + .. in it
+    int32_t n0;
 };
 
 // the op record of level l for image n: the launch's own, or - elementwise schemes (image_augmentations.py:563-570), every image its
 // own chain - the image's record in device memory.  A workgroup works on one image, so either way this is a scalar load.
+// the image a workgroup works on: blockIdx.y, or through the group order of a sorted elementwise batch (chb_aug_fused_items)
+__device__ __forceinline__ int fused_image(const FusedParams& P) { return P.order ? P.order[P.n0 + (int)blockIdx.y] : (int)blockIdx.y; }
+
 template <bool ITEMS>
 __device__ __forceinline__ const FusedOp& fused_op(const FusedParams& P, int n, int l) {
     if (ITEMS) return P.items[(int64_t)l * P.B + n];
@@ -1411,7 +1416,7 @@ struct FusedGather {
 #pragma unroll
             for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
         } else if (op == CHB_AUG_CUTOUT) {
-const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
+            const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool inside = cutout_inside<ITEMS>(P, L, C.n, ys[i], xs[i]);
@@ -1444,14 +1449,21 @@ struct FusedGather<-1, ITEMS> {
 //                 up), one affine evaluation per quad instead of four and no per-pixel gathers;
 //   FUSED_GENERAL everything else (per-pixel gathers below a warp, windows below a Sharpness);
 //   FUSED_ITEMS   as FUSED_GENERAL, the op records being each image's own (FusedParams::items: elementwise schemes).
-constexpr int FUSED_GENERAL = 0, FUSED_LOCAL = 1, FUSED_ROWS = 2, FUSED_ITEMS = 3;
+//   FUSED_ITEMS_LOCAL / FUSED_ITEMS_ROWS: the lean modes over per-image records - the images of an elementwise batch are sorted by
+//                 what their chain needs and every group gets its own launch (chb_aug_fused_items with an order).
+#ifndef CHB_ITEMS_GENERAL_RW
+#define CHB_ITEMS_GENERAL_RW 2
+#endif
+constexpr int FUSED_GENERAL = 0, FUSED_LOCAL = 1, FUSED_ROWS = 2, FUSED_ITEMS = 3, FUSED_ITEMS_LOCAL = 5, FUSED_ITEMS_ROWS = 6;
+constexpr bool mode_items(int m) { return m == FUSED_ITEMS || m == FUSED_ITEMS_LOCAL || m == FUSED_ITEMS_ROWS; }
+constexpr int mode_shape(int m) { return m == FUSED_ITEMS_LOCAL ? FUSED_LOCAL : (m == FUSED_ITEMS_ROWS ? FUSED_ROWS : (m == FUSED_ITEMS ? FUSED_GENERAL : m)); }
 struct __attribute__((aligned(4))) u32x4_a4 { uint32_t w[4]; };
 
 template <int L, int MODE>
 struct FusedQuad {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
-        constexpr bool ITEMS = MODE == FUSED_ITEMS;            // per-image records; otherwise as FUSED_GENERAL
-        constexpr bool GENERAL = MODE == FUSED_GENERAL || ITEMS;
+        constexpr bool ITEMS = mode_items(MODE);               // per-image records
+        constexpr bool GENERAL = mode_shape(MODE) == FUSED_GENERAL;
         const FusedOp& o = fused_op<ITEMS>(P, C.n, L);
         const int op = o.op;
         if (GENERAL && op == CHB_AUG_AFFINE) {
@@ -1519,7 +1531,7 @@ struct FusedQuad {
 #pragma unroll
             for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
         } else if (op == CHB_AUG_CUTOUT) {
-const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
+            const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool inside = cutout_inside<ITEMS>(P, L, C.n, y, x0 + i);
@@ -1542,10 +1554,10 @@ struct FusedQuad<-1, MODE> {
 
 // ---- FUSED_ROWS: four pixels of ONE row y of level L at columns xs[0..3] (a run x0 .. x0+3 at the top; under a warp whatever its
 // row map makes of them - for a pure shift again a run).  Level -1 loads a run with one 16-byte access, anything else per pixel.
-template <int L>
+template <int L, bool ITEMS = false>
 struct FusedRow {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, const int (&xs)[4], uint8_t (&b)[12]) {
-        const FusedOp& o = fused_op<false>(P, C.n, L);
+        const FusedOp& o = fused_op<ITEMS>(P, C.n, L);
         const int op = o.op;
         if (op == CHB_AUG_AFFINE) {             // f[3] == 0 (host): the source row does not depend on x
             const float fy = (float)y;
@@ -1571,23 +1583,23 @@ struct FusedRow {
                 for (int i = 0; i < 12; ++i) b[i] = fill;
                 return;
             }
-            FusedRow<L - 1>::at(P, C, (int)ry, x2, b);
+            FusedRow<L - 1, ITEMS>::at(P, C, (int)ry, x2, b);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) b[3 * i + c] = ok[i] ? b[3 * i + c] : fill;
             return;
         }
-        FusedRow<L - 1>::at(P, C, y, xs, b);
+        FusedRow<L - 1, ITEMS>::at(P, C, y, xs, b);
         if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
             const uint8_t* lut = C.lut + L * 768;
 #pragma unroll
             for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
         } else if (op == CHB_AUG_CUTOUT) {
-const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
+            const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool inside = cutout_inside(P, L, C.n, y, xs[i]);
+                const bool inside = cutout_inside<ITEMS>(P, L, C.n, y, xs[i]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? cutv : b[3 * i + c];
             }
@@ -1596,8 +1608,8 @@ const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
         }
     }
 };
-template <>
-struct FusedRow<-1> {
+template <bool ITEMS>
+struct FusedRow<-1, ITEMS> {
     static __device__ __forceinline__ void at(const FusedParams& P, const FusedCtx& C, int y, const int (&xs)[4], uint8_t (&b)[12]) {
         // A run (also one that leaves the row: those pixels are masked above): one 16-byte load from the dword below + byte
         // alignment.  Bytes in front of / behind this image belong to its neighbours in the batch; only the first and the last
@@ -1624,9 +1636,9 @@ struct FusedRow<-1> {
 // the quad (y, x0 .. x0+3) of the launch's top level
 template <int L, int MODE>
 __device__ __forceinline__ void fused_top_quad(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
-    if (MODE == FUSED_ROWS) {
+    if (mode_shape(MODE) == FUSED_ROWS) {
         const int xs[4] = {x0, x0 + 1, x0 + 2, x0 + 3};
-        FusedRow<L>::at(P, C, y, xs, b);
+        FusedRow<L, mode_items(MODE)>::at(P, C, y, xs, b);
     } else {
         FusedQuad<L, MODE>::at(P, C, y, x0, b);
     }
@@ -1652,8 +1664,8 @@ __device__ __forceinline__ int hist_slot(int bin) { return bin ^ ((bin >> 3) & 7
 template <int NLEV, int MODE>
 __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restrict__ in, int32_t* __restrict__ part, FusedParams P, int fast,
                                                          int minmax, int npop, int pop0, int pop1, int pop2) {
-    if (MODE == FUSED_ITEMS) {      // per-image chains: this image's op at the level - a table op at all, and which
-        const int op = fused_op<true>(P, blockIdx.y, NLEV < CHB_FUSED_MAX_OPS ? NLEV : 0).op;
+    if (mode_items(MODE)) {         // per-image chains: this image's op at the level - a table op at all, and which
+        const int op = fused_op<true>(P, fused_image(P), NLEV < CHB_FUSED_MAX_OPS ? NLEV : 0).op;
         if (op != CHB_AUG_AUTOCONTRAST && op != CHB_AUG_EQUALIZE) return;
         minmax = op == CHB_AUG_AUTOCONTRAST ? 1 : 0;
     }
@@ -1661,8 +1673,8 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
     int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) h[i] = 0;
-    const int n = blockIdx.y;
-    fused_stage_luts<MODE == FUSED_ITEMS>(P, n, lutS);
+    const int n = fused_image(P);
+    fused_stage_luts<mode_items(MODE)>(P, n, lutS);
     const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
     const int wq = (P.W + 3) >> 2;
     const int nq = P.H * wq;
@@ -1699,7 +1711,8 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
             }
         }
     }
-    int32_t* mine = part + ((int64_t)n * gridDim.x + blockIdx.x) * 768;
+    // the partial tables are indexed by the image, or - a sorted elementwise batch - by its position in the level's order
+    int32_t* mine = part + ((int64_t)(P.order ? P.n0 + (int)blockIdx.y : n) * gridDim.x + blockIdx.x) * 768;
     if (minmax) {      // AutoContrast needs the extremes only: slots 0 / 1 of each channel's partial table hold min / max
         __syncthreads();        // (the zeroing above is complete)
 #pragma unroll
@@ -1735,15 +1748,16 @@ template <int NLEV, bool PATCH, int MODE>
 __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw,
                                                           int fast) {
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
-    const int n = blockIdx.y;
-    fused_stage_luts<MODE == FUSED_ITEMS>(P, n, lutS);
+    const int n = fused_image(P);
+    fused_stage_luts<mode_items(MODE)>(P, n, lutS);
     const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = PATCH ? (gw * patch) >> 2 : (P.W + 3) >> 2;
     const int hh = PATCH ? gh * patch : P.H;
     // rows per wave: 8 where a quad is cheap (FUSED_ROWS, like fused_local_kernel: with 4 the per-workgroup set-up showed), 4 under the
     // per-pixel gathers of the general modes (8 measured 10 % slower there)
-    constexpr int RW = (MODE == FUSED_ROWS) ? 8 : 4;
+    // (per-image general chains: CHB_ITEMS_GENERAL_RW - workgroups of a mixed batch differ 10x in length, short ones balance better)
+    constexpr int RW = (mode_shape(MODE) == FUSED_ROWS) ? 8 : (MODE == FUSED_ITEMS ? CHB_ITEMS_GENERAL_RW : 4);
     const int row0 = blockIdx.x * (4 * RW) + wave * RW;
     const int K = patch * patch * 3;
     if (row0 >= hh) return;
@@ -1787,21 +1801,21 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
 // ---- FUSED_LOCAL chains, final pass: every level reads only its own pixel, so the launch is the normalise + patchify pass with the
 // chain applied to the quad between load and store - and it takes that kernel's shape (r03): 8 rows per wave, TWO quads per trip with
 // both loads issued before either chain runs.  grid = (groups of 32 rows, B).
-template <int L>
+template <int L, bool ITEMS = false>
 struct FusedApply {
     static __device__ __forceinline__ void on(const FusedParams& P, const FusedCtx& C, int y, int x0, uint8_t (&b)[12]) {
-        FusedApply<L - 1>::on(P, C, y, x0, b);
-        const FusedOp& o = P.ops[L];
+        FusedApply<L - 1, ITEMS>::on(P, C, y, x0, b);
+        const FusedOp& o = fused_op<ITEMS>(P, C.n, L);
         const int op = o.op;
         if (op == CHB_AUG_AUTOCONTRAST || op == CHB_AUG_EQUALIZE) {
             const uint8_t* lut = C.lut + L * 768;
 #pragma unroll
             for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
         } else if (op == CHB_AUG_CUTOUT) {
-const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
+            const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool inside = cutout_inside(P, L, C.n, y, x0 + i);
+                const bool inside = cutout_inside<ITEMS>(P, L, C.n, y, x0 + i);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) b[3 * i + c] = inside ? cutv : b[3 * i + c];
             }
@@ -1810,18 +1824,18 @@ const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
         }
     }
 };
-template <>
-struct FusedApply<-1> {
+template <bool ITEMS>
+struct FusedApply<-1, ITEMS> {
     static __device__ __forceinline__ void on(const FusedParams&, const FusedCtx&, int, int, uint8_t (&)[12]) {}
 };
 
-template <int NLEV, bool PATCH>
+template <int NLEV, bool PATCH, bool ITEMS = false>
 __global__ void __launch_bounds__(256) fused_local_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, FusedParams P, int patch, int gh, int gw,
                                                           int fast) {
     constexpr int ROWS = 8;
     __shared__ uint8_t lutS[CHB_FUSED_MAX_OPS * 768];
-    const int n = blockIdx.y;
-    fused_stage_luts(P, n, lutS);
+    const int n = fused_image(P);
+    fused_stage_luts<ITEMS>(P, n, lutS);
     const FusedCtx C{in + (int64_t)n * P.H * P.W * 3, lutS, n, fast != 0};
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wq = PATCH ? (gw * patch) >> 2 : (P.W + 3) >> 2;
@@ -1863,10 +1877,10 @@ __global__ void __launch_bounds__(256) fused_local_kernel(const uint8_t* __restr
         for (int i = 0; i < 12; ++i) bb[i] = 0;
         FusedQuad<-1, FUSED_LOCAL>::at(P, C, row0 + k, xq * 4, ba);
         if (two) FusedQuad<-1, FUSED_LOCAL>::at(P, C, row0 + k2, xq2 * 4, bb);
-        FusedApply<NLEV - 1>::on(P, C, row0 + k, xq * 4, ba);
+        FusedApply<NLEV - 1, ITEMS>::on(P, C, row0 + k, xq * 4, ba);
         emit(row0 + k, xq * 4, ba);
         if (two) {
-            FusedApply<NLEV - 1>::on(P, C, row0 + k2, xq2 * 4, bb);
+            FusedApply<NLEV - 1, ITEMS>::on(P, C, row0 + k2, xq2 * 4, bb);
             emit(row0 + k2, xq2 * 4, bb);
         }
         k = k2 + adv_k;
@@ -1974,7 +1988,7 @@ __global__ void __launch_bounds__(256) fused_sharp_kernel(const uint8_t* __restr
 #pragma unroll
                         for (int i = 0; i < 12; ++i) b[i] = lut[(i % 3) * 256 + b[i]];
                     } else if (o.op == CHB_AUG_CUTOUT) {
-const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
+                        const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const bool inside = cutout_inside(P, l, C.n, y, x0 + i);
@@ -2016,17 +2030,19 @@ const uint8_t cutv = (uint8_t)vgpr_byte(o.i3);
 // is the sum of the `slices` partial tables fused_hist_kernel left for the image (AutoContrast: min / max over their slots 0 / 1)
 // (items != NULL: the image's own op at the level, [B] records; an image without a table op there is skipped)
 __global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ tables, const int32_t* __restrict__ part, int slices, int op,
-                                                        const FusedOp* __restrict__ items = nullptr) {
+                                                        const FusedOp* __restrict__ items = nullptr, const int32_t* __restrict__ order = nullptr) {
     __shared__ int32_t s[256];
     __shared__ int32_t first_nz, last_nz;
     __shared__ int32_t hsave[256];
-    const int n = blockIdx.x / 3, c = blockIdx.x - 3 * n;
+    // order != NULL (sorted elementwise batch): workgroup triple `pos` belongs to image order[pos], its partial tables sit at pos
+    const int pos = blockIdx.x / 3, c = blockIdx.x - 3 * pos;
+    const int n = order ? order[pos] : pos;
     if (items) {
         op = items[n].op;
         if (op != CHB_AUG_AUTOCONTRAST && op != CHB_AUG_EQUALIZE) return;
     }
     const int t = threadIdx.x;
-    const int32_t* p0 = part + (int64_t)n * slices * 768 + c * 256 + t;
+    const int32_t* p0 = part + (int64_t)pos * slices * 768 + c * 256 + t;
     int32_t mine = 0;
     if (op == CHB_AUG_AUTOCONTRAST) {
         if (t < 2) {
@@ -2034,6 +2050,7 @@ __global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ ta
             for (int k = 1; k < slices; ++k) mine = (t == 0) ? min(mine, p0[(int64_t)k * 768]) : max(mine, p0[(int64_t)k * 768]);
         }
     } else {
+#pragma unroll 4
         for (int k = 0; k < slices; ++k) mine += p0[(int64_t)k * 768];
     }
     int32_t* h = hsave;
@@ -2072,7 +2089,7 @@ __global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ ta
             lut = lut < 0 ? 0 : (lut > 255 ? 255 : lut);
         }
     }
-    tables[(int64_t)blockIdx.x * 256 + t] = lut;
+    tables[((int64_t)n * 3 + c) * 256 + t] = lut;
 }
 
 const NormConst kCaffe = {{103.939f, 116.779f, 123.68f}, {1.f, 1.f, 1.f}};
@@ -2430,14 +2447,124 @@ int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, 
 // Per-image chains (the schemes' elementwise=True mode, image_augmentations.py:563-570 / augmentation_schemes.py:135): items_dev holds
 // one FusedOp per (level, image), [n_ops][B].  One final launch for the whole batch (+ a histogram pass and a table launch per level at
 // which some image has an AutoContrast / Equalize: `table_levels` bit l), every workgroup evaluating its own image's chain.
-int chb_aug_fused_items(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev, const int32_t* const* centers_dev,
-                        int table_levels, int32_t* workspace, int patch, void* stream) {
+// Sorting an elementwise batch by what its chains need (host).  Kind 0: pixel-local chains (fused_local_kernel), 1: no Sharpness and
+// warps that keep a row a row (FUSED_ROWS), 2: the rest (general evaluators; the chains with a Sharpness first - their workgroups run
+// longest, the short ones fill the tail).  Row 0 of `order_out` holds all images: kinds 0 .. 2 of the chains WITHOUT a table op, then
+// kinds 0 .. 2 of the chains with one (groups 3 .. 5: their final launch waits for the histogram passes, the others start at once);
+// row 1 + l the images with a table op at level l by the kind of the levels UNDER it (what the histogram pass evaluates; groups 0 .. 2).
+int chb_aug_items_sort(void* recs_host, int B, int H, int W, int n_ops, int32_t* order_out, int32_t* counts_out) {
+    if (B == 0) return CHB_OK;
+    if (!recs_host || !order_out || !counts_out || B < 0 || H <= 0 || W <= 0 || n_ops < 1 || n_ops > CHB_FUSED_MAX_OPS) return CHB_EINVAL;
+    FusedOp* recs = (FusedOp*)recs_host;
+    for (int l = 0; l < n_ops; ++l)
+        for (int n = 0; n < B; ++n) {
+            FusedOp& o = recs[(int64_t)l * B + n];
+            if (o.op < CHB_AUG_IDENTITY || o.op > CHB_AUG_CUTOUT) return CHB_EINVAL;
+            o.pad = (o.op == CHB_AUG_AFFINE && o.f[3] == 0.0f && affine_row_contiguous(o, H, W)) ? 1 : 0;
+        }
+    std::vector<int> key(B);       // 2 * group + (0: a Sharpness in the evaluated levels, 1: none), -1: not in this row
+    for (int row = 0; row <= n_ops; ++row) {
+        const int depth = row == 0 ? n_ops : row - 1;          // the levels the launch evaluates
+        int cnt[2 * CHB_ITEMS_GROUPS];
+        for (int k = 0; k < 2 * CHB_ITEMS_GROUPS; ++k) cnt[k] = 0;
+        for (int n = 0; n < B; ++n) {
+            key[n] = -1;
+            if (row > 0) {
+                const int op = recs[(int64_t)(row - 1) * B + n].op;
+                if (op != CHB_AUG_AUTOCONTRAST && op != CHB_AUG_EQUALIZE) continue;
+            }
+            bool local = true, rows = true, sharp = false, table = false;
+            for (int l = 0; l < depth; ++l) {
+                const FusedOp& o = recs[(int64_t)l * B + n];
+                local = local && fused_is_local(o.op);
+                rows = rows && o.op != CHB_AUG_SHARPNESS && (o.op != CHB_AUG_AFFINE || o.f[3] == 0.0f);
+                sharp = sharp || o.op == CHB_AUG_SHARPNESS;
+                table = table || o.op == CHB_AUG_AUTOCONTRAST || o.op == CHB_AUG_EQUALIZE;
+            }
+            const int g = (local ? 0 : (rows ? 1 : 2)) + ((row == 0 && table) ? 3 : 0);
+            key[n] = 2 * g + (sharp ? 0 : 1);
+            ++cnt[key[n]];
+        }
+        int at[2 * CHB_ITEMS_GROUPS], run = 0;
+        for (int k = 0; k < 2 * CHB_ITEMS_GROUPS; ++k) { at[k] = run; run += cnt[k]; }
+        int32_t* ord = order_out + (int64_t)row * B;
+        for (int n = 0; n < B; ++n) ord[n] = 0;
+        for (int n = 0; n < B; ++n)
+            if (key[n] >= 0) ord[at[key[n]]++] = n;
+        for (int g = 0; g < CHB_ITEMS_GROUPS; ++g) counts_out[row * CHB_ITEMS_GROUPS + g] = cnt[2 * g] + cnt[2 * g + 1];
+    }
+    return CHB_OK;
+}
+
+// The launches of a sorted batch are independent group by group, and each fills a fraction of the chip: the general chains without a
+// table op - the long pole - start at once on a side stream while the caller's stream walks the table levels (histogram passes of the
+// three kinds side by side on two more streams, then the table launch); then the other groups, one kind per stream; forked and joined
+// with events (inside a stream capture these become parallel branches of the graph).  Three side streams: the runtime has four
+// hardware queues, more streams share them and serialise.  One set per device, made on first use; the enqueue section holds the lock
+// (the events are shared).
+struct GroupStreams {
+    hipStream_t side[3];
+    hipEvent_t fork, join[3];
+    bool ok;
+};
+static std::mutex g_group_mu;
+static GroupStreams* group_streams() {
+    static GroupStreams sets[64];
+    static bool made[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!made[dev]) {
+        GroupStreams& g = sets[dev];
+        g.ok = hipEventCreateWithFlags(&g.fork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 3; ++k)
+            g.ok = g.ok && hipStreamCreateWithFlags(&g.side[k], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&g.join[k], hipEventDisableTiming) == hipSuccess;
+        made[dev] = true;
+    }
+    return sets[dev].ok ? &sets[dev] : nullptr;
+}
+
+// order_dev / counts: NULL (every image through the general evaluators, one launch), or what chb_aug_items_sort made of the records
+static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev, const int32_t* const* centers_dev,
+                           int table_levels, int32_t* workspace, int patch, const int32_t* order_dev, const int32_t* counts, void* stream) {
     if (B == 0) return CHB_OK;
     if (!in || !out || !items_dev || B < 0 || H <= 0 || W <= 0 || n_ops < 1 || n_ops > CHB_FUSED_MAX_OPS || patch < 0 || (patch & 3)) return CHB_EINVAL;
     if ((int64_t)H * W * 3 >= 2147483647LL - 4 || B > 65535) return CHB_EUNSUPPORTED;
     if (patch && (H / patch == 0 || W / patch == 0)) return CHB_EINVAL;
     if ((table_levels & ((1 << n_ops) - 1)) && !workspace) return CHB_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+    if ((order_dev == nullptr) != (counts == nullptr)) return CHB_EINVAL;
+    if (counts) {
+        for (int row = 0; row <= n_ops; ++row) {
+            int tot = 0;
+            for (int g = 0; g < CHB_ITEMS_GROUPS; ++g) {
+                const int c = counts[row * CHB_ITEMS_GROUPS + g];
+                if (c < 0 || (row > 0 && g >= 3 && c)) return CHB_EINVAL;
+                tot += c;
+            }
+            if (row == 0 ? tot != B : tot > B) return CHB_EINVAL;
+            if (row > 0 && tot > 0 && !(table_levels & (1 << (row - 1)))) return CHB_EINVAL;
+        }
+    }
+    hipStream_t s0 = (hipStream_t)stream;
+    hipStream_t s = s0;
+    std::unique_lock<std::mutex> lock(g_group_mu, std::defer_lock);
+    GroupStreams* gs = nullptr;
+    if (order_dev) {
+        lock.lock();
+        gs = group_streams();
+        if (!gs) return CHB_ELAUNCH;
+    }
+    auto fork = [&](int first, int last) -> bool {            // side streams first .. last wait for what the caller's stream holds so far
+        if (hipEventRecord(gs->fork, s0) != hipSuccess) return false;
+        for (int k = first; k <= last; ++k)
+            if (hipStreamWaitEvent(gs->side[k], gs->fork, 0) != hipSuccess) return false;
+        return true;
+    };
+    auto join = [&](int first, int last) -> bool {            // ... and the caller's stream for them
+        for (int k = first; k <= last; ++k)
+            if (hipEventRecord(gs->join[k], gs->side[k]) != hipSuccess || hipStreamWaitEvent(s0, gs->join[k], 0) != hipSuccess) return false;
+        return true;
+    };
     const FusedOp* items = (const FusedOp*)items_dev;
     FusedParams P;
     memset(&P, 0, sizeof(P));
@@ -2449,39 +2576,128 @@ int chb_aug_fused_items(const uint8_t* in, void* out, int B, int H, int W, int n
         P.centers[l] = centers_dev ? centers_dev[l] : nullptr;          // the [B,2] cutout centres of the level (images without a CutOut there ignore them)
         if (table_levels & (1 << l)) P.lut[l] = workspace + (int64_t)(n_tables++) * fused_table_ints(B, H, W);
     }
+    int gh = 0, gw = 0;
+    if (patch) { gh = H / patch; gw = W / patch; }
+    const int hh = patch ? gh * patch : H;
+#define CHB_ITEMS_FINAL_N(KERNEL_, ...)                                                                                                                \
+    switch (n_ops) {                                                                                                                                   \
+        case 1: KERNEL_(1, __VA_ARGS__); break;                                                                                                        \
+        case 2: KERNEL_(2, __VA_ARGS__); break;                                                                                                        \
+        case 3: KERNEL_(3, __VA_ARGS__); break;                                                                                                        \
+        default: KERNEL_(4, __VA_ARGS__); break;                                                                                                       \
+    }
+#define CHB_ITEMS_FINAL(NL, MODE_, GRID_)                                                                                                              \
+    do {                                                                                                                                               \
+        if (patch) hipLaunchKernelGGL((fused_final_kernel<NL, true, MODE_>), GRID_, dim3(256), 0, s, in, out, Q, patch, gh, gw, fast);                \
+        else hipLaunchKernelGGL((fused_final_kernel<NL, false, MODE_>), GRID_, dim3(256), 0, s, in, out, Q, patch, gh, gw, fast);                     \
+    } while (0)
+#define CHB_ITEMS_LOCAL(NL, GRID_)                                                                                                                     \
+    do {                                                                                                                                               \
+        if (patch) hipLaunchKernelGGL((fused_local_kernel<NL, true, true>), GRID_, dim3(256), 0, s, in, out, Q, patch, gh, gw, fast);                 \
+        else hipLaunchKernelGGL((fused_local_kernel<NL, false, true>), GRID_, dim3(256), 0, s, in, out, Q, patch, gh, gw, fast);                      \
+    } while (0)
+    // final launch of group g (kind g % 3) of row 0 on stream `on`
+    auto final_group = [&](int g, hipStream_t on) {
+        const int c = counts[g];
+        if (!c) return;
+        FusedParams Q = P;
+        Q.order = order_dev;
+        for (int k = 0; k < g; ++k) Q.n0 += counts[k];
+        s = on;
+        if (g % 3 == 0) {
+            const dim3 grid((hh + 31) / 32, c);
+            CHB_ITEMS_FINAL_N(CHB_ITEMS_LOCAL, grid);
+        } else if (g % 3 == 1) {
+            const dim3 grid((hh + 31) / 32, c);                 // FUSED_ROWS: 8 rows per wave
+            CHB_ITEMS_FINAL_N(CHB_ITEMS_FINAL, FUSED_ITEMS_ROWS, grid);
+        } else {
+            const dim3 grid((hh + 4 * CHB_ITEMS_GENERAL_RW - 1) / (4 * CHB_ITEMS_GENERAL_RW), c);
+            CHB_ITEMS_FINAL_N(CHB_ITEMS_FINAL, FUSED_ITEMS, grid);
+        }
+        s = s0;
+    };
+    if (order_dev) {            // the long pole - general chains without a table op - has nothing to wait for: beside the table levels
+        if (!fork(0, 0)) return CHB_ELAUNCH;
+        final_group(2, gs->side[0]);
+    }
     const int slices = slices_for((int64_t)H * W * 3, B);
     for (int l = 0; l < n_ops; ++l) {
         if (!P.lut[l]) continue;
         int32_t* t = const_cast<int32_t*>(P.lut[l]);
         int32_t* part = t + (int64_t)B * 768;
-        const dim3 grid(slices, B);
-#define CHB_ITEMS_HIST(NL) hipLaunchKernelGGL((fused_hist_kernel<NL, FUSED_ITEMS>), grid, dim3(256), 0, s, in, part, P, fast, 0, 0, -2, -2, -2)
-        switch (l) {
-            case 0: CHB_ITEMS_HIST(0); break;
-            case 1: CHB_ITEMS_HIST(1); break;
-            case 2: CHB_ITEMS_HIST(2); break;
-            default: CHB_ITEMS_HIST(3); break;
+#define CHB_ITEMS_HIST(NL, MODE_) hipLaunchKernelGGL((fused_hist_kernel<NL, MODE_>), grid, dim3(256), 0, s, in, part, Q, fast, 0, 0, -2, -2, -2)
+#define CHB_ITEMS_HIST_L(MODE_)                                                                                                                       \
+    switch (l) {                                                                                                                                      \
+        case 0: CHB_ITEMS_HIST(0, MODE_); break;                                                                                                      \
+        case 1: CHB_ITEMS_HIST(1, MODE_); break;                                                                                                      \
+        case 2: CHB_ITEMS_HIST(2, MODE_); break;                                                                                                      \
+        default: CHB_ITEMS_HIST(3, MODE_); break;                                                                                                     \
+    }
+        if (!order_dev) {
+            const FusedParams& Q = P;
+            const dim3 grid(slices, B);
+            CHB_ITEMS_HIST_L(FUSED_ITEMS);
+            hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, part, slices, 0, items + (int64_t)l * B, (const int32_t*)nullptr);
+            continue;
         }
+        // the images with a table op at this level only, in their own launch per kind; fewer images take more slices each - up to 16:
+        // the table launch adds them up one after the other (the partial tables of `tot` images x `sl` slices fit where B x slices
+        // were reserved)
+        const int32_t* cn = counts + (l + 1) * CHB_ITEMS_GROUPS;
+        const int tot = cn[0] + cn[1] + cn[2];
+        if (tot == 0) continue;
+        int sl = slices_for((int64_t)H * W * 3, tot);
+        if (sl > 16) sl = 16 > slices ? 16 : slices;
+        if ((int64_t)sl * tot > (int64_t)slices * B) sl = (int)(((int64_t)slices * B) / tot);
+        FusedParams Q = P;
+        Q.order = order_dev + (int64_t)(l + 1) * B;
+        const bool spread = (cn[0] != 0) + (cn[1] != 0) + (cn[2] != 0) > 1;
+        if (spread && !fork(1, 2)) return CHB_ELAUNCH;
+        for (int g = 0; g < 3; ++g) {
+            if (cn[g]) {
+                const dim3 grid(sl, cn[g]);
+                s = (g == 2 || !spread) ? s0 : gs->side[1 + g];
+                if (g == 0) { CHB_ITEMS_HIST_L(FUSED_ITEMS_LOCAL); }
+                else if (g == 1) { CHB_ITEMS_HIST_L(FUSED_ITEMS_ROWS); }
+                else { CHB_ITEMS_HIST_L(FUSED_ITEMS); }
+            }
+            Q.n0 += cn[g];
+        }
+        s = s0;
+        if (spread && !join(1, 2)) return CHB_ELAUNCH;
+        hipLaunchKernelGGL(fused_lut_kernel, dim3(tot * 3), dim3(256), 0, s, t, part, sl, 0, items + (int64_t)l * B, Q.order);
+#undef CHB_ITEMS_HIST_L
 #undef CHB_ITEMS_HIST
-        hipLaunchKernelGGL(fused_lut_kernel, dim3(B * 3), dim3(256), 0, s, t, part, slices, 0, items + (int64_t)l * B);
     }
-    int gh = 0, gw = 0;
-    if (patch) { gh = H / patch; gw = W / patch; }
-    const dim3 grid(((patch ? gh * patch : H) + 15) / 16, B);
-#define CHB_ITEMS_FINAL(NL)                                                                                                                            \
-    do {                                                                                                                                               \
-        if (patch) hipLaunchKernelGGL((fused_final_kernel<NL, true, FUSED_ITEMS>), grid, dim3(256), 0, s, in, out, P, patch, gh, gw, fast);  \
-        else hipLaunchKernelGGL((fused_final_kernel<NL, false, FUSED_ITEMS>), grid, dim3(256), 0, s, in, out, P, patch, gh, gw, fast);       \
-    } while (0)
-    switch (n_ops) {
-        case 1: CHB_ITEMS_FINAL(1); break;
-        case 2: CHB_ITEMS_FINAL(2); break;
-        case 3: CHB_ITEMS_FINAL(3); break;
-        default: CHB_ITEMS_FINAL(4); break;
+    if (!order_dev) {
+        const FusedParams& Q = P;
+        const dim3 grid((hh + 4 * CHB_ITEMS_GENERAL_RW - 1) / (4 * CHB_ITEMS_GENERAL_RW), B);
+        CHB_ITEMS_FINAL_N(CHB_ITEMS_FINAL, FUSED_ITEMS, grid);
+    } else {                    // everything else behind the table launches: one kind per stream
+        if (!fork(1, 2)) return CHB_ELAUNCH;
+        final_group(5, s0);
+        final_group(0, gs->side[1]);
+        final_group(3, gs->side[1]);
+        final_group(1, gs->side[2]);
+        final_group(4, gs->side[2]);
+        if (!join(0, 2)) return CHB_ELAUNCH;
     }
+#undef CHB_ITEMS_LOCAL
 #undef CHB_ITEMS_FINAL
+#undef CHB_ITEMS_FINAL_N
     CHB_LAUNCH_CHECK();
     return CHB_OK;
+}
+
+int chb_aug_fused_items(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev, const int32_t* const* centers_dev,
+                        int table_levels, int32_t* workspace, int patch, void* stream) {
+    return fused_items_run(in, out, B, H, W, n_ops, items_dev, centers_dev, table_levels, workspace, patch, nullptr, nullptr, stream);
+}
+
+int chb_aug_fused_items_sorted(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev, const int32_t* const* centers_dev,
+                               int table_levels, int32_t* workspace, int patch, const int32_t* order_dev, const int32_t* counts_host, void* stream) {
+    if (B > 0 && (!order_dev || !counts_host)) return CHB_EINVAL;
+    return fused_items_run(in, out, B, H, W, n_ops, items_dev, centers_dev, table_levels, workspace, patch, order_dev, counts_host, stream);
 }
 
 int chb_aug_sharpness(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, float factor, void* stream) {

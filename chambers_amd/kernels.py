@@ -132,6 +132,7 @@ def aug_dispatch(x, items, out=None):
 
 FUSED_OP_DTYPE = np.dtype([("op", np.int32), ("i", np.int32, (4,)), ("f", np.float32, (6,)), ("pad", np.int32)])   # 48 bytes
 FUSED_MAX_OPS = 4
+ITEMS_GROUPS = 6          # CHB_ITEMS_GROUPS: columns of chb_aug_items_sort's counts
 
 
 class AugPlan:
@@ -218,9 +219,12 @@ class AugItemsPlan:
     def __len__(self):
         return int(self.items.shape[0])
 
-    def resident(self, device):
-        """(device records [n*B, 48] uint8, per-level cutout-centre tensors or None, table-level bit mask)"""
-        if self._resident is None or self._resident[0].device != device:
+    def resident(self, device, h=None, w=None):
+        """(device records [n*B, 48] uint8, per-level cutout-centre tensors or None, table-level bit mask, group order, group counts).
+        With the image size given the images are sorted by what their chains need (chb_aug_items_sort: device int32 [(1+n)*B] order
+        + host int32 [(1+n)*6] counts, for chb_aug_fused_items_sorted); without it the last two are None."""
+        key = (device, h, w)
+        if self._resident is None or self._resident[0] != key:
             items = self.items
             n, b = items.shape
             recs = np.zeros((n, b), dtype=FUSED_OP_DTYPE)
@@ -234,13 +238,19 @@ class AugItemsPlan:
                     tables |= 1 << l
                 # the dispatch record carries a CutOut's centre in i0, i1; the chain evaluators read a [B,2] table
                 centers.append(_upload(np.ascontiguousarray(items[l]["i"][:, :2], dtype=np.int32), device) if (ops == _lib.AUG_CUTOUT).any() else None)
-            self._resident = (_upload(recs.view(np.uint8).reshape(n * b, FUSED_OP_DTYPE.itemsize), device), centers, tables)
-        return self._resident
+            order = counts = None
+            if h is not None and b and 1 <= n <= FUSED_MAX_OPS:
+                order_host = np.zeros(((1 + n), b), dtype=np.int32)
+                counts = np.zeros((1 + n) * ITEMS_GROUPS, dtype=np.int32)
+                _lib.call("chb_aug_items_sort", recs.ctypes.data, b, int(h), int(w), n, order_host.ctypes.data, counts.ctypes.data)
+                order = _upload(order_host.reshape(-1), device)
+            self._resident = (key, (_upload(recs.view(np.uint8).reshape(n * b, FUSED_OP_DTYPE.itemsize), device), centers, tables, order, counts))
+        return self._resident[1]
 
 
 def aug_fused_items(x, items, patch=None, out=None):
-    """The whole per-image chain in ONE launch (chb_aug_fused_items; + a histogram pass and a table launch per slot in which some
-    image drew AutoContrast / Equalize).  items: [n_slots, B] AUG_ITEM_DTYPE or an AugItemsPlan; patch as for aug_fused."""
+    """The whole per-image chains, the images sorted by what their chain needs and one launch per group (chb_aug_fused_items_sorted;
+    + histogram passes and a table launch per slot in which some image drew AutoContrast / Equalize).  items: [n_slots, B] AUG_ITEM_DTYPE or an AugItemsPlan; patch as for aug_fused."""
     x = _u8_nhwc(x)
     b, h, w, c = x.shape
     if c != 3:
@@ -249,7 +259,7 @@ def aug_fused_items(x, items, patch=None, out=None):
     n = len(plan)
     if plan.items.shape[1] != b or not 1 <= n <= FUSED_MAX_OPS:
         raise ValueError("expected [1..%d, %d] op records, got %s" % (FUSED_MAX_OPS, b, plan.items.shape))
-    dev_items, centers, tables = plan.resident(x.device)
+    dev_items, centers, tables, order, counts = plan.resident(x.device, h, w)
     cptr = (ctypes.c_void_p * n)()
     for l, cen in enumerate(centers):
         if cen is not None:
@@ -266,8 +276,10 @@ def aug_fused_items(x, items, patch=None, out=None):
             out = torch.empty((rows, patch * patch * 3), dtype=torch.bfloat16, device=x.device)
         if out.dtype != torch.bfloat16 or out.numel() < rows * patch * patch * 3 or not out.is_contiguous():
             raise ValueError("out must be a contiguous bf16 buffer of at least %d patch rows" % rows)
-    _lib.call("chb_aug_fused_items", _lib.ptr(x), _lib.ptr(out), b, h, w, n, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables,
-              _lib.ptr(ws), 0 if patch is None else int(patch), _s())
+    if b == 0:
+        return out
+    _lib.call("chb_aug_fused_items_sorted", _lib.ptr(x), _lib.ptr(out), b, h, w, n, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables,
+              _lib.ptr(ws), 0 if patch is None else int(patch), _lib.ptr(order), counts.ctypes.data, _s())
     return out
 
 

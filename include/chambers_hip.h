@@ -347,6 +347,22 @@ int chb_aug_fused(const uint8_t* in, void* out, int B, int H, int W, int n_ops, 
  * (+ a histogram pass and a table launch per set bit); out as for chb_aug_fused.  Bit-identical to the ops applied image by image. */
 int chb_aug_fused_items(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev,
                         const int32_t* const* centers_dev, int table_levels, int32_t* workspace, int patch, void* stream);
+/* The elementwise stage with the images SORTED by what their chains need, so that every group runs the evaluator the batch-shared
+ * launches would pick for it (same reference lines as chb_aug_fused_items; the reference maps the images one by one, any order of
+ * evaluation gives its bytes).  chb_aug_items_sort (host only): recs_host = the [n_ops][B] records before upload - the `pad` member of
+ * warps that are pure row shifts on H x W is set in place; order_out int32 [1 + n_ops][B]: row 0 = every image, in six groups - the
+ * chains WITHOUT an AutoContrast / Equalize by kind (pixel-local | no Sharpness and only warps that keep rows | the rest, chains with a
+ * Sharpness first), then the chains with one by kind; row 1 + l = the images with an AutoContrast / Equalize at level l by the kind of
+ * the levels under it (groups 0 .. 2); counts_out int32 [1 + n_ops][CHB_ITEMS_GROUPS] = the group sizes.
+ * chb_aug_fused_items_sorted: order_dev = that array in device memory, counts_host = the counts; everything else as
+ * chb_aug_fused_items.  One final launch per non-empty group and a histogram launch per (table level, non-empty kind) over the images
+ * that need one; the chains without tables run beside the histogram passes (the groups are independent: caller's stream + internal
+ * side streams, forked and joined by events inside the call, capturable).  Same bytes as chb_aug_fused_items. */
+#define CHB_ITEMS_GROUPS 6
+int chb_aug_items_sort(void* recs_host, int B, int H, int W, int n_ops, int32_t* order_out, int32_t* counts_out);
+int chb_aug_fused_items_sorted(const uint8_t* in, void* out, int B, int H, int W, int n_ops, const void* items_dev,
+                               const int32_t* const* centers_dev, int table_levels, int32_t* workspace, int patch,
+                               const int32_t* order_dev, const int32_t* counts_host, void* stream);
 /* int32 elements of chb_aug_fused's workspace for a chain with n_tables AutoContrast / Equalize ops (0 for none): host arithmetic only. */
 int64_t chb_aug_fused_workspace_ints(int B, int H, int W, int n_tables);
 

@@ -203,8 +203,74 @@ def test_per_image_cutout_without_a_centre_table_is_left_out():
     dec = [[{"op": 14, "negate": False, "centers": (5, 6)}, {"op": 2, "negate": False, "centers": (1, 1)}] for _ in range(3)]
     plan = aug.RandAugment(2, 9, elementwise=True).items_plan(shape, dec)
     xd = _dev(x)
-    dev_items, _centers, tables = plan.resident(xd.device)
+    dev_items, _centers, tables = plan.resident(xd.device)[:3]
     out = torch.empty_like(xd)
     cptr = (ctypes.c_void_p * 2)()          # no centre tables at all
     _lib.call("chb_aug_fused_items", _lib.ptr(xd), _lib.ptr(out), 3, 20, 24, 2, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables, None, 0, K._s())
     _eq(out, A.invert(x), "CutOut without centres -> Invert alone")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n_slots,patch", [((64, 48, 64, 3), 2, 0), ((40, 32, 48, 3), 3, 16), ((9, 21, 30, 3), 4, 0), ((1, 16, 16, 3), 2, 0)])
+def test_sorted_groups_give_the_bytes_of_the_single_launch(shape, n_slots, patch):
+    """chb_aug_fused_items_sorted (one launch per group of chains, histograms over the images that need one, more slices for fewer
+    images) against chb_aug_fused_items (every image through the general evaluators) and the oracle, table ops at every level."""
+    import ctypes
+    from chambers_amd import _lib
+    from chambers_amd import augmentations as aug
+    from chambers_amd import kernels as K
+    b, h, w, _ = shape
+    g = np.random.Generator(np.random.PCG64(700 + n_slots + b))
+    x = _img(shape, 31 + b)
+    dec = _rand_decisions(g, n_slots, b, h, w)
+    layer = aug.RandAugment(n_slots, 9, elementwise=True)
+    plan = layer.items_plan(shape, dec)
+    xd = _dev(x)
+    dev_items, centers, tables, order, counts = plan.resident(xd.device, h, w)
+    assert int(counts[:K.ITEMS_GROUPS].sum()) == b
+    cptr = (ctypes.c_void_p * n_slots)()
+    for l, c_ in enumerate(centers):
+        if c_ is not None:
+            cptr[l] = c_.data_ptr()
+    nt = bin(tables).count("1")
+    ws = torch.empty(max(_lib.aug_fused_workspace_ints(b, h, w, nt), 1), dtype=torch.int32, device=xd.device)
+    if patch:
+        one = torch.empty((b * (h // patch) * (w // patch), patch * patch * 3), dtype=torch.bfloat16, device=xd.device)
+    else:
+        one = torch.empty_like(xd)
+    _lib.call("chb_aug_fused_items", _lib.ptr(xd), _lib.ptr(one), b, h, w, n_slots, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables,
+              _lib.ptr(ws), patch, K._s())
+    grouped = K.aug_fused_items(xd, plan, patch=patch or None)
+    torch.cuda.synchronize()
+    assert torch.equal(grouped.view(torch.uint8) if not patch else grouped.view(torch.int16), one.view(torch.uint8) if not patch else one.view(torch.int16))
+    if not patch:
+        _eq(grouped, A.rand_augment_elementwise(x, n_slots, 9, dec), "sorted groups vs oracle")
+
+
+@pytest.mark.gpu
+def test_sorted_entry_checks_its_group_counts():
+    import ctypes
+    from chambers_amd import _lib
+    from chambers_amd import augmentations as aug
+    from chambers_amd import kernels as K
+    shape = (4, 16, 16, 3)
+    g = np.random.Generator(np.random.PCG64(5))
+    dec = _rand_decisions(g, 2, 4, 16, 16)
+    plan = aug.RandAugment(2, 9, elementwise=True).items_plan(shape, dec)
+    xd = _dev(_img(shape, 3))
+    dev_items, centers, tables, order, counts = plan.resident(xd.device, 16, 16)
+    cptr = (ctypes.c_void_p * 2)()
+    for l, c_ in enumerate(centers):
+        if c_ is not None:
+            cptr[l] = c_.data_ptr()
+    ws = torch.empty(max(_lib.aug_fused_workspace_ints(4, 16, 16, 2), 1), dtype=torch.int32, device=xd.device)
+    out = torch.empty_like(xd)
+    bad = counts.copy()
+    bad[0] += 1                                    # group sizes of row 0 must add up to B
+    lib = _lib.load()
+    rc = lib.chb_aug_fused_items_sorted(_lib.ptr(xd), _lib.ptr(out), 4, 16, 16, 2, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables,
+                                        _lib.ptr(ws), 0, _lib.ptr(order), bad.ctypes.data, K._s())
+    assert rc == _lib.CHB_EINVAL
+    rc = lib.chb_aug_fused_items_sorted(_lib.ptr(xd), _lib.ptr(out), 4, 16, 16, 2, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables,
+                                        _lib.ptr(ws), 0, None, counts.ctypes.data, K._s())
+    assert rc == _lib.CHB_EINVAL

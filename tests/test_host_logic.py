@@ -206,3 +206,55 @@ def test_distilled_parameter_table_and_weight_roundtrip():
     assert keras_variable_names(cfg)["add_cls_token/embeddings"] == ["add_cls_token/embeddings:0", "add_dist_token/embeddings:0"]
     with pytest.raises(ValueError):
         ViTConfig(16, 128, 2, 2, 256, distilled=True, feature_dim=64)
+
+
+def test_items_sort_groups_counts_and_row_shift_flags():
+    """chb_aug_items_sort (host only, no GPU): images of an elementwise batch sorted by what their chain needs - chains without a table op
+    by kind (pixel-local | warps that keep rows | the rest, chains with a Sharpness first), then chains with one by kind - for the whole
+    chain (row 0) and, per table level, by the kind of the levels under it; `pad` marks pure row shifts."""
+    from chambers_amd import _lib
+    from chambers_amd import kernels as K
+    n = 2
+    G = K.ITEMS_GROUPS
+
+    def affine(f):
+        r = np.zeros((), dtype=K.FUSED_OP_DTYPE)
+        r["op"] = _lib.AUG_AFFINE
+        r["f"] = np.asarray(f, dtype=np.float32)
+        return r
+
+    shift = affine([1, 0, 10, 0, 1, 0])            # TranslateX: a pure row shift
+    rot = affine([0.9, 0.4, 0, -0.4, 0.9, 0])      # rows do not stay rows
+    #            level 0                level 1
+    chains = [(_lib.AUG_INVERT,        _lib.AUG_EQUALIZE),      # 0  local, table at level 1 under a local level
+              (shift,                  _lib.AUG_AUTOCONTRAST),  # 1  rows, table at level 1 under a row warp
+              (rot,                    _lib.AUG_EQUALIZE),      # 2  general, table at level 1 under a general warp
+              (_lib.AUG_EQUALIZE,      shift),                  # 3  rows, table at level 0 (nothing under it)
+              (_lib.AUG_SHARPNESS,     _lib.AUG_INVERT),        # 4  general, in front of 6
+              (_lib.AUG_CUTOUT,        _lib.AUG_POSTERIZE),     # 5  local
+              (_lib.AUG_IDENTITY,      rot),                    # 6  general
+              (shift,                  _lib.AUG_SHARPNESS),     # 7  general, in front of 6
+              (_lib.AUG_SHARPNESS,     _lib.AUG_EQUALIZE),      # 8  general with a table, in front of 2
+              (_lib.AUG_BRIGHTNESS,    _lib.AUG_INVERT),        # 9  local
+              (_lib.AUG_INVERT,        shift)]                  # 10 rows
+    b = len(chains)
+    recs = np.zeros((n, b), dtype=K.FUSED_OP_DTYPE)
+    for i, (a, c) in enumerate(chains):
+        for l, v in enumerate((a, c)):
+            if isinstance(v, np.ndarray):
+                recs[l, i] = v
+            else:
+                recs[l, i]["op"] = v
+    order = np.full((1 + n, b), -1, dtype=np.int32)
+    counts = np.zeros((1 + n) * G, dtype=np.int32)
+    _lib.call("chb_aug_items_sort", recs.ctypes.data, b, 32, 48, n, order.ctypes.data, counts.ctypes.data)
+    counts = counts.reshape(1 + n, G)
+    assert counts.tolist() == [[2, 1, 3, 1, 2, 2], [1, 0, 0, 0, 0, 0], [1, 1, 2, 0, 0, 0]]
+    assert order[0].tolist() == [5, 9, 10, 4, 7, 6, 0, 1, 3, 8, 2]
+    assert order[1, :1].tolist() == [3]
+    assert order[2, :4].tolist() == [0, 1, 8, 2]              # under the table of chain 8 sits a Sharpness: general, and first
+    assert recs["pad"][0].tolist() == [0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0] and recs["pad"][1].tolist() == [0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1]
+    bad = recs.copy()
+    bad[0, 0]["op"] = 99
+    with pytest.raises(ValueError):
+        _lib.call("chb_aug_items_sort", bad.ctypes.data, b, 32, 48, n, order.ctypes.data, counts.ctypes.data)

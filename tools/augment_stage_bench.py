@@ -20,6 +20,7 @@ if os.environ.get("CHB_AB_LIB"):
     from chambers_amd import _build
     _build.LIB_PATH = os.path.abspath(os.environ["CHB_AB_LIB"])
 FUSED_ONLY = os.environ.get("CHB_STAGE_FUSED_ONLY", "0") == "1"
+ELEM_ONLY = os.environ.get("CHB_STAGE_ELEMENTWISE_ONLY", "0") == "1"      # the per-image stage alone (for rocprofv3 --kernel-trace)
 from chambers_amd import augmentations as aug
 from chambers_amd import kernels as K
 
@@ -59,6 +60,8 @@ def decisions(a, b):
 
 rows = {}
 for a, b in itertools.product(range(16), range(16)):
+    if ELEM_ONLY:
+        break
     dec = decisions(a, b)
     plan = layer.plan(x.shape, dec)
     t_fused = timed(lambda: K.aug_fused(x, plan, patch=16, out=patches))
@@ -101,16 +104,35 @@ def elementwise_stage_r02():          # rounds 1-2: one dispatch launch per slot
 
 
 items_plan = K.AugItemsPlan(items)
-items_plan.resident(x.device)
+items_plan.resident(x.device, H, W)
 torch.cuda.synchronize()
 
 
-def elementwise_stage():              # round 3: every image's chain inside ONE final launch (chb_aug_fused_items)
+def elementwise_stage():              # round 3: every image's chain inside the patchify pass, images sorted by what the chain needs
     K.aug_fused_items(x, items_plan, patch=16, out=patches)
 
 
+def elementwise_stage_unsorted():     # the same with every image through the general evaluators (chb_aug_fused_items, one final launch)
+    import ctypes
+    dev_items, cen, tables, _o, _c = items_plan.resident(x.device, H, W)
+    cptr = (ctypes.c_void_p * 2)()
+    for l, c_ in enumerate(cen):
+        if c_ is not None:
+            cptr[l] = c_.data_ptr()
+    _lib.call("chb_aug_fused_items", _lib.ptr(x), _lib.ptr(patches), B, H, W, 2, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables,
+              _lib.ptr(ws_items), 16, K._s())
+
+
+ws_items = torch.empty(_lib.aug_fused_workspace_ints(B, H, W, 2), dtype=torch.int32, device="cuda")
 t_elem_r02 = timed(elementwise_stage_r02)
 t_elem = timed(elementwise_stage)
+t_elem_unsorted = timed(elementwise_stage_unsorted)
+if ELEM_ONLY and os.environ.get("CHB_STAGE_TRACE", "0") == "1":      # one replay of each route, for a kernel trace
+    sys.exit(0)
+if ELEM_ONLY:
+    print("elementwise, per-image chains: sorted by group %.1f us; one launch %.1f us; dispatch x2 %.1f us; groups %s"
+          % (t_elem, t_elem_unsorted, t_elem_r02, items_plan.resident(x.device, H, W)[4].reshape(-1, K.ITEMS_GROUPS).tolist()))
+    sys.exit(0)
 t_patch = timed(lambda: K.normalize_patchify(x, 16, "tf", out=patches))
 
 fused = np.array([v[0] for v in rows.values()])
@@ -119,7 +141,8 @@ gbps = lambda us: stage_bytes / us / 1e3     # noqa: E731
 print("stage = RandAugment(2,9) chain -> normalise('tf') -> bf16 patch rows, batch [%d,%d,%d,3]; algorithmic bytes %.1f MB" % (B, H, W, stage_bytes / 1e6))
 print("%-32s %10s %12s %10s" % ("", "us", "alg. GB/s", "of 8 TB/s"))
 for label, us in (("normalise + patchify alone", t_patch), ("fused, mean of 256 pairs", fused.mean()), ("op-by-op, mean of 256 pairs", ops.mean()),
-                  ("elementwise, per-image chains", t_elem), ("elementwise, dispatch x2 (r02)", t_elem_r02)):
+                  ("elementwise, chains by group", t_elem), ("elementwise, chains, 1 launch", t_elem_unsorted),
+                  ("elementwise, dispatch x2 (r02)", t_elem_r02)):
     print("%-32s %10.1f %12.1f %9.1f%%" % (label, us, gbps(us), 100 * gbps(us) / 8000))
 print("fused: min %.1f us (%s), max %.1f us (%s)" % (fused.min(), list(rows)[int(fused.argmin())], fused.max(), list(rows)[int(fused.argmax())]))
 print("op-by-op: min %.1f us (%s), max %.1f us (%s)" % (ops.min(), list(rows)[int(ops.argmin())], ops.max(), list(rows)[int(ops.argmax())]))
@@ -133,5 +156,5 @@ for title, col in (("fused stage, us (row = first op, column = second op)", 0), 
     for a in names:
         print("%-13s" % a + "".join("%7.0f" % rows[a + ">" + b][col] for b in names))
 print(json.dumps({"batch": B, "size": H, "stage_bytes": stage_bytes, "patchify_us": t_patch, "fused_mean_us": float(fused.mean()),
-                  "op_by_op_mean_us": float(ops.mean()), "elementwise_us": t_elem, "elementwise_dispatch_us": t_elem_r02,
+                  "op_by_op_mean_us": float(ops.mean()), "elementwise_us": t_elem, "elementwise_one_launch_us": t_elem_unsorted, "elementwise_dispatch_us": t_elem_r02,
                   "pairs": {k: [round(v[0], 1), round(v[1], 1)] for k, v in rows.items()}}))
