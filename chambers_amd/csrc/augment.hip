@@ -2237,7 +2237,9 @@ static bool fused_is_local(int op) { return op != CHB_AUG_AFFINE && op != CHB_AU
 // d(y) the rounded source column of x = 0?  (Not so where a source column is an exact tie: half-away rounding flips with the sign and
 // with the binade of the sum - ShearX by -0.27 on rows 50 and 150 of a 224-row image.)  Decided by evaluating the device's own expression (same float order, this file is built without contraction) at
 // every pixel, once per (coefficients, H, W): RandAugment draws a sign, not a magnitude, so a run sees two records per op.
-static bool affine_row_contiguous(const FusedOp& o, int H, int W) {
+// `budget` (optional): evaluations this caller may still pay for - a per-image sort of records with free-running coefficients would
+// otherwise walk H x W pixels per image; past the budget the answer is "no" (always correct: the per-pixel path), uncached.
+static bool affine_row_contiguous(const FusedOp& o, int H, int W, int* budget = nullptr) {
     if (o.f[0] != 1.0f || o.f[3] != 0.0f) return false;
     struct Entry { float f[6]; int H, W; bool yes; };
     static std::mutex mu;
@@ -2245,6 +2247,7 @@ static bool affine_row_contiguous(const FusedOp& o, int H, int W) {
     std::lock_guard<std::mutex> lock(mu);
     for (const Entry& e : seen)
         if (e.H == H && e.W == W && !memcmp(e.f, o.f, sizeof(e.f))) return e.yes;
+    if (budget && (*budget)-- <= 0) return false;
     bool yes = true;
     for (int y = 0; y < H && yes; ++y) {
         const float fy = (float)y;
@@ -2456,11 +2459,12 @@ int chb_aug_items_sort(void* recs_host, int B, int H, int W, int n_ops, int32_t*
     if (B == 0) return CHB_OK;
     if (!recs_host || !order_out || !counts_out || B < 0 || H <= 0 || W <= 0 || n_ops < 1 || n_ops > CHB_FUSED_MAX_OPS) return CHB_EINVAL;
     FusedOp* recs = (FusedOp*)recs_host;
+    int budget = 32;            // pure-shift checks this call pays for (the schemes draw signs, not magnitudes: a handful of records)
     for (int l = 0; l < n_ops; ++l)
         for (int n = 0; n < B; ++n) {
             FusedOp& o = recs[(int64_t)l * B + n];
             if (o.op < CHB_AUG_IDENTITY || o.op > CHB_AUG_CUTOUT) return CHB_EINVAL;
-            o.pad = (o.op == CHB_AUG_AFFINE && o.f[3] == 0.0f && affine_row_contiguous(o, H, W)) ? 1 : 0;
+            o.pad = (o.op == CHB_AUG_AFFINE && o.f[3] == 0.0f && affine_row_contiguous(o, H, W, &budget)) ? 1 : 0;
         }
     std::vector<int> key(B);       // 2 * group + (0: a Sharpness in the evaluated levels, 1: none), -1: not in this row
     for (int row = 0; row <= n_ops; ++row) {

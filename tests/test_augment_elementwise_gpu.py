@@ -274,3 +274,40 @@ def test_sorted_entry_checks_its_group_counts():
     rc = lib.chb_aug_fused_items_sorted(_lib.ptr(xd), _lib.ptr(out), 4, 16, 16, 2, _lib.ptr(dev_items), ctypes.cast(cptr, ctypes.c_void_p), tables,
                                         _lib.ptr(ws), 0, None, counts.ctypes.data, K._s())
     assert rc == _lib.CHB_EINVAL
+
+
+def test_sorted_groups_inside_a_captured_graph_and_on_a_side_stream():
+    """The group launches fork onto the library's side streams and join again inside the call: captured into a HIP graph they must
+    replay as one unit (new input bytes in the same buffers -> new output), and on a caller's non-default stream they must order with it."""
+    from chambers_amd import augmentations as aug
+    from chambers_amd import kernels as K
+    shape = (48, 32, 48, 3)
+    b, h, w, _ = shape
+    g = np.random.Generator(np.random.PCG64(77))
+    dec = _rand_decisions(g, 2, b, h, w)
+    for n in range(16):
+        dec[n][0]["op"] = n                       # every op, tables included
+        dec[16 + n][1]["op"] = n
+    layer = aug.RandAugment(2, 9, elementwise=True)
+    plan = layer.items_plan(shape, dec)
+    x1, x2 = _img(shape, 1), _img(shape, 2)
+    xd = _dev(x1).clone()
+    out = torch.empty_like(xd)
+    plan.resident(xd.device, h, w)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            K.aug_fused_items(xd, plan, out=out)
+        direct = out.clone()
+    side.synchronize()
+    _eq(direct, A.rand_augment_elementwise(x1, 2, 9, dec), "sorted groups on a side stream")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        K.aug_fused_items(xd, plan, out=out)
+    for x in (x2, x1):
+        xd.copy_(_dev(x))
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        _eq(out, A.rand_augment_elementwise(x, 2, 9, dec), "sorted groups replayed from a graph")
