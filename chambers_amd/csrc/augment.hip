@@ -1451,8 +1451,8 @@ struct FusedGather<-1, ITEMS> {
 //   FUSED_ITEMS   as FUSED_GENERAL, the op records being each image's own (FusedParams::items: elementwise schemes).
 //   FUSED_ITEMS_LOCAL / FUSED_ITEMS_ROWS: the lean modes over per-image records - the images of an elementwise batch are sorted by
 //                 what their chain needs and every group gets its own launch (chb_aug_fused_items with an order).
-#ifndef CHB_ITEMS_GENERAL_RW
-#define CHB_ITEMS_GENERAL_RW 2
+#ifndef CHB_GENERAL_TILES
+#define CHB_GENERAL_TILES 1          // A/B: 0 = the row-long mapping in the general launches too
 #endif
 constexpr int FUSED_GENERAL = 0, FUSED_LOCAL = 1, FUSED_ROWS = 2, FUSED_ITEMS = 3, FUSED_ITEMS_LOCAL = 5, FUSED_ITEMS_ROWS = 6;
 constexpr bool mode_items(int m) { return m == FUSED_ITEMS || m == FUSED_ITEMS_LOCAL || m == FUSED_ITEMS_ROWS; }
@@ -1685,21 +1685,39 @@ __global__ void __launch_bounds__(256) fused_hist_kernel(const uint8_t* __restri
     int y = q / wq, xq = q - y * wq;
     const int pops[3] = {pop0, pop1, pop2};
     int cnt[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};        // [popular value][channel], wave-uniform (scalar registers)
-    for (; q < nq; q += stride) {
+    // general chains (per-pixel gathers): 16 x 16 pixel tiles per wave as in fused_final_kernel, the image's tiles dealt round the
+    // slice's waves; lanes of a tile that hangs over the image stay in the loop (the ballots below) and count nothing
+    constexpr bool TILED = CHB_GENERAL_TILES && mode_shape(MODE) == FUSED_GENERAL && NLEV > 0;
+    const int tiles_x = (wq + 3) >> 2, tiles = tiles_x * ((P.H + 15) >> 4);
+    const int lane = threadIdx.x & 63;
+    int t = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int t_stride = gridDim.x * (blockDim.x >> 6);
+    for (; TILED ? t < tiles : q < nq; q += stride, t += t_stride) {
+        bool valid = true;
+        if (TILED) {
+            const int ty = t / tiles_x;
+            y = ty * 16 + (lane >> 2);
+            xq = (t - ty * tiles_x) * 4 + (lane & 3);
+            valid = (y < P.H) && (xq < wq);
+        }
         const int x0 = xq * 4;
         uint8_t b[12];
-        fused_top_quad<NLEV - 1, MODE>(P, C, y, x0, b);
-        y += adv_y;
-        xq += adv_x;
-        if (xq >= wq) { xq -= wq; ++y; }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) b[i] = 0;
+        if (valid) fused_top_quad<NLEV - 1, MODE>(P, C, y, x0, b);
+        if (!TILED) {
+            y += adv_y;
+            xq += adv_x;
+            if (xq >= wq) { xq -= wq; ++y; }
+        }
         if (minmax) {
 #pragma unroll
             for (int i = 0; i < 12; ++i)
-                if (x0 + i / 3 < P.W) { lo[i % 3] = min(lo[i % 3], (int)b[i]); hi[i % 3] = max(hi[i % 3], (int)b[i]); }
+                if (valid && x0 + i / 3 < P.W) { lo[i % 3] = min(lo[i % 3], (int)b[i]); hi[i % 3] = max(hi[i % 3], (int)b[i]); }
         } else {
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
-                const int v = (x0 + i / 3 < P.W) ? (int)b[i] : -1;
+                const int v = (valid && x0 + i / 3 < P.W) ? (int)b[i] : -1;
                 bool rare = v >= 0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
@@ -1756,22 +1774,15 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
     const int hh = PATCH ? gh * patch : P.H;
     // rows per wave: 8 where a quad is cheap (FUSED_ROWS, like fused_local_kernel: with 4 the per-workgroup set-up showed), 4 under the
     // per-pixel gathers of the general modes (8 measured 10 % slower there)
-    // (per-image general chains: CHB_ITEMS_GENERAL_RW - workgroups of a mixed batch differ 10x in length, short ones balance better)
-    constexpr int RW = (mode_shape(MODE) == FUSED_ROWS) ? 8 : (MODE == FUSED_ITEMS ? CHB_ITEMS_GENERAL_RW : 4);
+    constexpr int RW = (mode_shape(MODE) == FUSED_ROWS) ? 8 : 4;
     const int row0 = blockIdx.x * (4 * RW) + wave * RW;
     const int K = patch * patch * 3;
-    if (row0 >= hh) return;
-    const int nrows = min(RW, hh - row0);
     // The wave's RW rows x wq quads as one index space: all 64 lanes busy whatever the row length.  No integer division in the loop
     // (r03: five of them per quad - idx / wq and the patch coordinates - cost more vector instructions than a pixel-local chain
     // itself): (row, quad) advance by 64 quads per trip, and a power-of-two patch edge (16, 32: every ViT of the zoo) turns the patch
     // coordinates into shifts and masks; other edges keep the division.
     const int ps = (PATCH && (patch & (patch - 1)) == 0) ? (31 - __builtin_clz(patch)) : -1;     // uniform
-    int k = 0, xq = lane;
-    while (xq >= wq) { xq -= wq; ++k; }
-    const int adv_k = 64 / wq, adv_x = 64 - adv_k * wq;       // 64 quads = adv_k whole rows + adv_x quads (uniform, once per wave)
-    for (; k < nrows; ) {
-        const int y = row0 + k, x0 = xq * 4;
+    auto quad = [&](int y, int x0) {
         uint8_t b[12];
         fused_top_quad<NLEV - 1, MODE>(P, C, y, x0, b);
         if (PATCH) {
@@ -1792,6 +1803,26 @@ __global__ void __launch_bounds__(256) fused_final_kernel(const uint8_t* __restr
             if (C.fast) store_quad<true>(orow, x0, P.W, b);
             else store_quad<false>(orow, x0, P.W, b);
         }
+    };
+    if (CHB_GENERAL_TILES && mode_shape(MODE) == FUSED_GENERAL) {
+        // General chains gather per pixel: a wave takes 16 x 16 pixel TILES of the workgroup's 16-row band (lane = row of the tile x
+        // quad), so that one gather instruction covers a compact block - under a rotation its source is a rotated block of ~22 x 22
+        // pixels, some thirty cache lines, where the 256 x 1 strip of the row-long mapping crosses more than a hundred - and with
+        // 16-pixel patches the wave writes one whole patch row (1536 contiguous bytes).
+        const int y = blockIdx.x * 16 + (lane >> 2);
+        for (int t = wave; t * 4 < wq; t += 4) {
+            const int xq = t * 4 + (lane & 3);
+            if (y < hh && xq < wq) quad(y, xq * 4);
+        }
+        return;
+    }
+    if (row0 >= hh) return;
+    const int nrows = min(RW, hh - row0);
+    int k = 0, xq = lane;
+    while (xq >= wq) { xq -= wq; ++k; }
+    const int adv_k = 64 / wq, adv_x = 64 - adv_k * wq;       // 64 quads = adv_k whole rows + adv_x quads (uniform, once per wave)
+    for (; k < nrows; ) {
+        quad(row0 + k, xq * 4);
         k += adv_k;
         xq += adv_x;
         if (xq >= wq) { xq -= wq; ++k; }
@@ -2615,7 +2646,7 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
             const dim3 grid((hh + 31) / 32, c);                 // FUSED_ROWS: 8 rows per wave
             CHB_ITEMS_FINAL_N(CHB_ITEMS_FINAL, FUSED_ITEMS_ROWS, grid);
         } else {
-            const dim3 grid((hh + 4 * CHB_ITEMS_GENERAL_RW - 1) / (4 * CHB_ITEMS_GENERAL_RW), c);
+            const dim3 grid((hh + 15) / 16, c);
             CHB_ITEMS_FINAL_N(CHB_ITEMS_FINAL, FUSED_ITEMS, grid);
         }
         s = s0;
@@ -2675,7 +2706,7 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
     }
     if (!order_dev) {
         const FusedParams& Q = P;
-        const dim3 grid((hh + 4 * CHB_ITEMS_GENERAL_RW - 1) / (4 * CHB_ITEMS_GENERAL_RW), B);
+        const dim3 grid((hh + 15) / 16, B);
         CHB_ITEMS_FINAL_N(CHB_ITEMS_FINAL, FUSED_ITEMS, grid);
     } else {                    // everything else behind the table launches: one kind per stream
         if (!fork(1, 2)) return CHB_ELAUNCH;
