@@ -2063,7 +2063,6 @@ __global__ void __launch_bounds__(256) fused_sharp_kernel(const uint8_t* __restr
 __global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ tables, const int32_t* __restrict__ part, int slices, int op,
                                                         const FusedOp* __restrict__ items = nullptr, const int32_t* __restrict__ order = nullptr) {
     __shared__ int32_t s[256];
-    __shared__ int32_t first_nz, last_nz;
     __shared__ int32_t hsave[256];
     // order != NULL (sorted elementwise batch): workgroup triple `pos` belongs to image order[pos], its partial tables sit at pos
     const int pos = blockIdx.x / 3, c = blockIdx.x - 3 * pos;
@@ -2084,15 +2083,10 @@ __global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ ta
 #pragma unroll 4
         for (int k = 0; k < slices; ++k) mine += p0[(int64_t)k * 768];
     }
-    int32_t* h = hsave;
-    h[t] = mine;
-    s[t] = mine;
-    if (t == 0) { first_nz = 255; last_nz = 0; }
-    __syncthreads();
-    if (mine != 0) { atomicMax(&last_nz, t); atomicMin(&first_nz, t); }
-    __syncthreads();
     int32_t lut = t;
     if (op == CHB_AUG_AUTOCONTRAST) {
+        s[t] = mine;
+        __syncthreads();
         const float lo = (float)s[0], hi = (float)s[1];      // the statistics pass left min / max in slots 0 / 1
         const float rng = hi - lo;
         float sc = (rng != 0.0f) ? 255.0f / rng : 0.0f;
@@ -2105,16 +2099,28 @@ __global__ void __launch_bounds__(256) fused_lut_kernel(int32_t* __restrict__ ta
         v = fminf(fmaxf(v, 0.0f), 255.0f);
         lut = (int32_t)trunc_u8(v);
     } else {
-        for (int o = 1; o < 256; o <<= 1) {
-            const int32_t v = (t >= o) ? s[t - o] : 0;
-            __syncthreads();
-            s[t] += v;
-            __syncthreads();
+        // inclusive sum over the 256 bins: shuffles inside each wave, the four wave totals through LDS (one barrier; r03: the
+        // 8-step LDS scan with its 16 barriers was most of this launch's 13 us); the last occupied bin from the waves' ballots
+        const int lane = t & 63, w = t >> 6;
+        int32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
         }
-        const int32_t total = s[255];
-        const int32_t excl = s[t] - mine;
-        const int32_t step = (total - h[last_nz]) / 255;
+        const unsigned long long nz = __ballot(mine != 0);
+        if (lane == 63) s[w] = incl;
+        if (lane == 0) s[4 + w] = nz ? (w * 64 + 63 - __builtin_clzll(nz)) : 0;
+        hsave[t] = mine;
         __syncthreads();
+        int32_t base = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) base += (k < w) ? s[k] : 0;
+        incl += base;
+        const int32_t total = s[0] + s[1] + s[2] + s[3];
+        const int32_t last = max(max(s[4], s[5]), max(s[6], s[7]));        // 0 for an empty histogram, as before
+        const int32_t excl = incl - mine;
+        const int32_t step = (total - hsave[last]) / 255;
         if (step != 0) {
             lut = (excl + step / 2) / step;
             lut = lut < 0 ? 0 : (lut > 255 ? 255 : lut);
