@@ -18,11 +18,28 @@ def _s():
     return _lib.stream_ptr()
 
 
+_COPY_STREAMS = {}
+
+
 def _upload(array, device):
-    """Host array -> device tensor through pinned memory, asynchronously on the current stream: a pageable copy would make the
-    host wait for everything already queued on the stream (the previous training step)."""
-    t = torch.from_numpy(np.ascontiguousarray(array))
-    return t.pin_memory().to(device, non_blocking=True)
+    """Host array -> device tensor through pinned memory on a COPY stream of its own, the current stream waiting for its event: the
+    transfer runs at once - while the previous training step still computes - instead of at the point of the compute stream where it
+    was issued (an in-stream copy makes the stream drain, hand over to the DMA engine and pick up again: ~0.3 ms of idle GPU per
+    uploaded plan in the elementwise bench; a pageable copy would moreover make the host wait for everything queued)."""
+    t = torch.from_numpy(np.ascontiguousarray(array)).pin_memory()
+    device = torch.device(device)
+    cur = torch.cuda.current_stream(device)
+    if torch.cuda.is_current_stream_capturing():
+        return t.to(device, non_blocking=True)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    cs = _COPY_STREAMS.get(key)
+    if cs is None:
+        cs = _COPY_STREAMS[key] = torch.cuda.Stream(device)
+    with torch.cuda.stream(cs):
+        d = t.to(device, non_blocking=True)
+    cur.wait_event(cs.record_event())
+    d.record_stream(cur)
+    return d
 
 
 def _u8_nhwc(x):
