@@ -184,7 +184,7 @@ class AutoAugment(Layer):
 
     def _elementwise(self, inputs, decisions):
         """elementwise=True (:135, RandomChoice :563-570): every image draws its own sub-policy, its two chance draws and its
-        sign draws.  The two steps of the 25 sub-policies run as one launch, each workgroup its own image's pair (chb_aug_fused_items)."""
+        sign draws.  The two steps of the 25 sub-policies run inside the patchify pass, each workgroup its own image's pair, the images sorted by what the pair needs (chb_aug_fused_items_sorted)."""
         from .. import kernels as K
         b = inputs.shape[0]
         if b == 0:

@@ -495,8 +495,8 @@ class RandomChoice(Layer):
     def _elementwise(self, inputs, choices, slot_kwargs):
         """tf.map_fn over batch-1 tensors (:565-567): every image draws its own transform index per slot, and the chosen
         transform sees a batch of one (its sign draw, cutout centre and Contrast's constant are per image).  When every
-        transform can describe itself as an op record, the whole call is ONE launch for the whole batch, each workgroup
-        evaluating its own image's chain (chb_aug_fused_items; chains longer than the fused kernels hold: one dispatch launch per
+        transform can describe itself as an op record, the whole batch runs at once, each workgroup evaluating its own image's
+        chain and the images sorted by what their chain needs (chb_aug_fused_items_sorted; chains longer than the fused kernels hold: one dispatch launch per
         slot, chb_aug_dispatch); transforms that cannot (user-supplied layers) take the image-by-image route."""
         b = inputs.shape[0]
         if b == 0:
@@ -511,7 +511,7 @@ class RandomChoice(Layer):
         h, w = int(inputs.shape[1]), int(inputs.shape[2])
         items = self.elementwise_items(b, h, w, choices, slot_kwargs)
         if self.n_transforms <= K.FUSED_MAX_OPS:
-            return K.aug_fused_items(inputs, items)        # every image's chain in one launch (chb_aug_fused_items)
+            return K.aug_fused_items(inputs, items)        # every image's own chain, one launch per group of chains (chb_aug_fused_items_sorted)
         x = inputs
         for i in range(self.n_transforms):
             x = K.aug_dispatch(x, items[i])
