@@ -2537,11 +2537,11 @@ int chb_aug_items_sort(void* recs_host, int B, int H, int W, int n_ops, int32_t*
     return CHB_OK;
 }
 
-// The launches of a sorted batch are independent group by group, and each fills a fraction of the chip: the general chains without a
-// table op - the long pole - start at once on a side stream while the caller's stream walks the table levels (histogram passes of the
-// three kinds side by side on two more streams, then the table launch); then the other groups, one kind per stream; forked and joined
-// with events (inside a stream capture these become parallel branches of the graph).  Three side streams: the runtime has four
-// hardware queues, more streams share them and serialise.  One set per device, made on first use; the enqueue section holds the lock
+// The launches of a sorted batch are independent group by group, and each fills a fraction of the chip: the chains without a table op
+// start at once on two side streams - the general ones, the long pole, alone on theirs - while the caller's stream and a third side
+// stream walk the table levels (histogram passes, then the table launch) and then run the chains with tables; forked and joined with
+// events (inside a stream capture these become parallel branches of the graph).  Three side streams and no more: the runtime has four
+// hardware queues, a fifth stream shares one and serialises behind whatever runs there (measured: 234 us against 215).  One set per device, made on first use; the enqueue section holds the lock
 // (the events are shared).
 struct GroupStreams {
     hipStream_t side[3];
@@ -2657,9 +2657,11 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
         }
         s = s0;
     };
-    if (order_dev) {            // the long pole - general chains without a table op - has nothing to wait for: beside the table levels
-        if (!fork(0, 0)) return CHB_ELAUNCH;
+    if (order_dev) {            // the chains without a table op have nothing to wait for: beside the table levels, the long pole alone
+        if (!fork(0, 2)) return CHB_ELAUNCH;
         final_group(2, gs->side[0]);
+        final_group(0, gs->side[1]);
+        final_group(1, gs->side[1]);
     }
     const int slices = slices_for((int64_t)H * W * 3, B);
     for (int l = 0; l < n_ops; ++l) {
@@ -2693,11 +2695,11 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
         FusedParams Q = P;
         Q.order = order_dev + (int64_t)(l + 1) * B;
         const bool spread = (cn[0] != 0) + (cn[1] != 0) + (cn[2] != 0) > 1;
-        if (spread && !fork(1, 2)) return CHB_ELAUNCH;
+        if (spread && !fork(2, 2)) return CHB_ELAUNCH;
         for (int g = 0; g < 3; ++g) {
             if (cn[g]) {
                 const dim3 grid(sl, cn[g]);
-                s = (g == 2 || !spread) ? s0 : gs->side[1 + g];
+                s = (g == 2 || !spread) ? s0 : gs->side[2];
                 if (g == 0) { CHB_ITEMS_HIST_L(FUSED_ITEMS_LOCAL); }
                 else if (g == 1) { CHB_ITEMS_HIST_L(FUSED_ITEMS_ROWS); }
                 else { CHB_ITEMS_HIST_L(FUSED_ITEMS); }
@@ -2705,7 +2707,7 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
             Q.n0 += cn[g];
         }
         s = s0;
-        if (spread && !join(1, 2)) return CHB_ELAUNCH;
+        if (spread && !join(2, 2)) return CHB_ELAUNCH;
         hipLaunchKernelGGL(fused_lut_kernel, dim3(tot * 3), dim3(256), 0, s, t, part, sl, 0, items + (int64_t)l * B, Q.order);
 #undef CHB_ITEMS_HIST_L
 #undef CHB_ITEMS_HIST
@@ -2714,12 +2716,10 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
         const FusedParams& Q = P;
         const dim3 grid((hh + 15) / 16, B);
         CHB_ITEMS_FINAL_N(CHB_ITEMS_FINAL, FUSED_ITEMS, grid);
-    } else {                    // everything else behind the table launches: one kind per stream
-        if (!fork(1, 2)) return CHB_ELAUNCH;
+    } else {                    // the chains with tables behind the table launches
+        if ((counts[3] || counts[4]) && !fork(2, 2)) return CHB_ELAUNCH;
         final_group(5, s0);
-        final_group(0, gs->side[1]);
-        final_group(3, gs->side[1]);
-        final_group(1, gs->side[2]);
+        final_group(3, gs->side[2]);
         final_group(4, gs->side[2]);
         if (!join(0, 2)) return CHB_ELAUNCH;
     }
