@@ -3,7 +3,7 @@
 (BASELINE.json `metric`; workload = configs[2]: on-GPU RandAugment(n=2, m=9) -> normalise -> forward ->
 softmax-CE -> backward -> AdamW, batch 512 per GPU, bf16 MFMA compute / fp32 master weights).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N = 1..8; for N > 1 the command starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -278,6 +278,65 @@ def ensure_library(local_rank):
         time.sleep(2.0)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this same script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, one per GPU), relay their output (only rank 0 prints the JSON line), return non-zero when any rank
+    fails or the job exceeds CHB_BENCH_TIMEOUT seconds (default 1800).  This parent makes no HIP call at any point
+    (`torch.cuda.device_count()` does not initialise the GPU on this image) and never exec()s; a failed or overdue job is ended by
+    killing exactly the process groups started here."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    if args.backend == "nccl" and torch.cuda.device_count() < n:
+        print("bench.py: --gpus %d on backend nccl (RCCL) needs %d GPUs, this node shows %d (RCCL refuses two ranks on one device; "
+              "--backend gloo rehearses N ranks on fewer GPUs)" % (n, n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    timeout = float(os.environ.get("CHB_BENCH_TIMEOUT", "1800"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0 inherits stdout (its one JSON line is the job's); the other ranks' stdout goes to stderr so nothing else can land there
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)      # the group this launcher created for that rank, nothing else
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            p.wait()
+
+    deadline = time.time() + timeout
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                print("bench.py: rank %d exited with code %d; stopping the other ranks" % bad[0], file=sys.stderr)
+                rc = bad[0][1] if bad[0][1] > 0 else 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                print("bench.py: %d-rank job exceeded %.0f s (CHB_BENCH_TIMEOUT); killing it" % (n, timeout), file=sys.stderr)
+                rc = 124
+                break
+            time.sleep(0.2)
+    finally:
+        kill_all()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,13 +359,19 @@ def main():
                     help="dtype the gradient slices are all-reduced in (bf16: half the bytes, one extra rounding per contribution)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU) and the N ranks are
+        # fresh children
+        raise SystemExit(spawn_ranks(args))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (one process per GPU)" % args.gpus)
         args.gpus = world
+    if args.backend == "nccl" and world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks on backend nccl (RCCL) need %d GPUs, this node shows %d (RCCL refuses two ranks on one "
+                         "device; --backend gloo rehearses N ranks on fewer GPUs)" % (world, world, torch.cuda.device_count()))
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     ensure_library(int(os.environ.get("LOCAL_RANK", "0")))

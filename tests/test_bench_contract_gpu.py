@@ -51,6 +51,28 @@ def test_two_rank_launch_over_gloo():
     assert d["cpu_baseline"] is None
 
 
+def test_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher - the parent never touches the GPU, starts two fresh rank
+    processes and relays rank 0's one JSON line (gloo: the box has one GPU and RCCL refuses two ranks on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "32", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["dp"]["world_size"] == 2 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["dp"]["collectives_per_step"] == 13 and d["dp"]["backend"] == "gloo"
+    assert abs(d["value"] - 2 * 32 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert d["cpu_baseline"] is None
+
+
+def test_plain_command_refuses_more_rccl_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 2 and "needs %d GPUs" % n in r.stderr and not r.stdout.strip()
+
+
 @pytest.mark.parametrize("payload", ["fp32", "bf16"])
 def test_forced_single_rank_rccl_group(payload):
     """`--force-dp` initialises a ONE-rank `nccl` (= RCCL) process group on the one GPU there is and drives the
