@@ -967,6 +967,385 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_head_kernel(const bf16_t* __
     }
 }
 
+// ------------------------------------------------------------------------------------ backward, persistent pipelined kernel
+// 193 <= N <= 208 (ViT at 224^2 / patch 16 with one or two special tokens: 13 key tiles, 7 query blocks).  Same arithmetic as
+// attn_bwd_head_kernel in the same order - the outputs are bit-identical - but the workgroup is PERSISTENT (one per CU, walking
+// heads blockIdx.x, blockIdx.x + gridDim.x, ...) and nothing of a head is loaded "up front": the lean kernel spends half of its time
+// (tools/attn_ablate.py: 0.28 of 0.56 ms) moving a head's 200 KB with the CU otherwise idle, because one 16-wave workgroup is all a
+// CU holds (128 registers x 16 waves, 125 KiB of LDS) and its prologue / epilogue cannot overlap another head's arithmetic.
+// Here the unit of work is a STEP = one 32-query block of one head, and the steps of all the workgroup's heads form one stream:
+//  * Q / dO / keep-bit rows of a block are only read during that block's step, so they live in a ring of RING = 4 slots (9 KiB
+//    each) instead of whole-head images; wave 15 (the PRODUCER) issues the LDS-DMA pieces of step p + 3 at step p and - one step
+//    later, through registers - the O / dO rows whose dot products are delta = rowsum(dO * O), plus lse;
+//  * K (both dS.K operands of phase B and the row fragments of phase A) and V are whole-head images: K double-buffered (phase B of a
+//    head's last block runs during the first step of the next head), V single (read once, at a head's first step); waves 13 / 14
+//    run phase B one step behind and issue the next head's K / V pieces during steps 1 .. 4 of the current head;
+//  * waves 0 .. 12 own a key tile each (phase A) exactly as in the lean kernel; dK / dV leave with fire-and-forget stores at a head's
+//    last step; one LDS-only barrier per step, none around head boundaries.
+// Ordering (loads, stores and LDS-DMA of a wave retire in issue order): only the producer issues loads, and it consumes its register
+// loads one barrier after issuing them - that data dependence is the only wait, see the producer loop.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+__device__ __forceinline__ uint32_t lds_addr32(const void* p) { return (uint32_t)(uintptr_t)LDS_PTR(p); }
+// LDS-DMA piece (64 lanes x 16 bytes -> 1 KiB at lds_wave_base) as inline asm: hipcc's wait-count pass must not know these are
+// LDS-DMA.  Measured on this kernel's ISA: with the builtin in the producer's loop, the pass put an s_waitcnt vmcnt(0) in front of
+// the first transposed LDS read / dS^T store of EVERY iteration of the phase A and phase B loops too (loops of other waves, which no
+// path connects to the producer's) - each dQ / dK / dV store would then be waited for, round trip to HBM included, one step later.
+// m0 (the LDS base of the piece) is written inside the asm and not listed as a clobber (hipcc warns that it is a reserved register;
+// it never holds a compiler value here: gfx950 DS instructions take no m0 and the kernel uses no builtin LDS-DMA, movrel or sendmsg -
+// tools/check_pipe_isa.py checks that every m0 write in the kernel's ISA is one of these asm statements).
+__device__ __forceinline__ void glds16_pipe(const void* src, const void* lds_wave_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_addr32(lds_wave_base));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");   // m0 is reserved (not allocatable): the asm owns it, see the note above
+}
+
+__device__ __forceinline__ void glds4_pipe(const void* src, const void* lds_wave_base) {      // 64 lanes x 4 bytes
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_addr32(lds_wave_base));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "memory");   // m0 is reserved (not allocatable): the asm owns it, see the note above
+}
+
+namespace pipe {
+constexpr int NKT = 13, NQB = 7, NP = 224, RING = 4, ORING = 3;
+constexpr int SLOT_ELEMS = 32 * HD;                              // bf16 elements of one Q / dO / O ring slot (4 KiB)
+constexpr size_t OFF_Q = 0;
+constexpr size_t OFF_G = OFF_Q + (size_t)RING * SLOT_ELEMS * 2;
+constexpr size_t OFF_O = OFF_G + (size_t)RING * SLOT_ELEMS * 2;
+constexpr size_t OFF_BITS = OFF_O + (size_t)ORING * SLOT_ELEMS * 2;
+constexpr size_t OFF_LSE = OFF_BITS + (size_t)RING * 1024;       // 256 bytes a slot: raw lse by LDS-DMA (64 lanes x 4 bytes), fixed up in place
+constexpr size_t OFF_DELTA = OFF_LSE + (size_t)RING * 256;
+constexpr size_t OFF_K = OFF_DELTA + (size_t)RING * 128;
+constexpr size_t OFF_V = OFF_K + (size_t)2 * NP * HD * 2;
+constexpr size_t OFF_DST = OFF_V + (size_t)NKT * 16 * HD * 2;
+constexpr size_t LDS_BYTES = OFF_DST + (size_t)2 * NP * 64;      // 163,328 of the CU's 163,840 bytes
+static_assert(LDS_BYTES <= 160 * 1024, "the pipelined attention backward needs the whole LDS of a CU, not more");
+}  // namespace pipe
+
+template <bool DROP>
+__global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                             const uint32_t* __restrict__ drop_bits, int N, int H, int total_heads, float scale,
+                                                             float scale_log2, float drop_scale, int dbg) {
+    const int dbg_period = dbg & 1023;          // timing experiments (tools/attn_pipe_check.py): results are WRONG when dbg != 0
+    const bool dbg_no_b = dbg & 1024, dbg_no_prod = dbg & 2048, dbg_no_acc = dbg & 4096, dbg_no_soft = dbg & 8192;
+    using namespace pipe;
+    constexpr int NTP = NP / 32;
+    constexpr int NDMA = DROP ? 14 : 13;           // producer pieces per step: Q 4, dO 4, O 4, lse 1, keep bits 1
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* ringQ = reinterpret_cast<bf16_t*>(smem_raw + OFF_Q);
+    bf16_t* ringG = reinterpret_cast<bf16_t*>(smem_raw + OFF_G);
+    bf16_t* ringO = reinterpret_cast<bf16_t*>(smem_raw + OFF_O);
+    uint32_t* ringBits = reinterpret_cast<uint32_t*>(smem_raw + OFF_BITS);
+    float* ringLse = reinterpret_cast<float*>(smem_raw + OFF_LSE);
+    float* ringDelta = reinterpret_cast<float*>(smem_raw + OFF_DELTA);
+    bf16_t* Kimg = reinterpret_cast<bf16_t*>(smem_raw + OFF_K);       // [2][NP][64]
+    bf16_t* Vimg = reinterpret_cast<bf16_t*>(smem_raw + OFF_V);       // [16 NKT][64]
+    char* dST = smem_raw + OFF_DST;                                    // [2][NP keys][64 bytes]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const int nh = (total_heads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // heads of this workgroup (>= 1)
+    const int T = nh * NQB;                                                                 // its steps
+    const int r8 = lane >> 3, c8 = lane & 7;
+
+    // one K or V image piece = 8 rows x 128 bytes (rows >= N re-read row N - 1: finite, and every use of them is masked)
+    auto kv_piece = [&](int bh, int which, int inst, bf16_t* img) {
+        const int b = bh / H, h = bh - b * H;
+        const int r = inst * 8 + r8;
+        const bf16_t* src = qkv + ((int64_t)b * N + min(r, N - 1)) * D3 + (int64_t)which * Dm + h * HD + ((c8 ^ swz_dual(r)) << 3);
+        glds16_pipe(src, img + inst * 512);
+    };
+
+    // ---- prologue: zero dS^T (rows of dead key tiles stay zero for good), first head's K / V, the producer's first three steps
+    for (int id = tid; id < 2 * NP * 4; id += 1024) reinterpret_cast<uint4*>(dST)[id] = make_uint4(0, 0, 0, 0);
+    if (wave == 13) {
+        for (int inst = 0; inst < NP / 8; ++inst) kv_piece((int)blockIdx.x, 1, inst, Kimg);
+    } else if (wave == 14) {
+        for (int inst = 0; inst < NKT * 2; ++inst) kv_piece((int)blockIdx.x, 2, inst, Vimg);
+    }
+
+    // ---- producer pieces.  Everything the producer moves goes global -> LDS by LDS-DMA (inline asm, see glds16_pipe); delta and the
+    // scaled lse of a step are formed from LDS two iterations after its pieces were issued (asm LDS reads: a DS instruction hipcc can
+    // see behind a pending LDS-DMA gets a vmcnt(0) in front), so no iteration waits for a round trip to HBM it has just started.
+    auto step_head = [&](int tp, int& bh, int& q0) {       // step index -> (head, first query)
+        const int k = tp / NQB;
+        bh = (int)blockIdx.x + k * (int)gridDim.x;
+        q0 = 32 * (tp - k * NQB);
+    };
+    auto prod_dma = [&](int tp, int islot) {               // NDMA pieces of step tp -> ring slots of stream position islot
+        int bh, q0;
+        step_head(tp, bh, q0);
+        const int b = bh / H, h = bh - b * H;
+        const int slot = islot & (RING - 1), oslot = islot % ORING;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int r = 8 * pc + r8;
+            const int64_t row = (int64_t)b * N + min(q0 + r, N - 1);
+            const int sw = (c8 ^ swz_dual(r)) << 3;
+            glds16_pipe(qkv + row * D3 + h * HD + sw, ringQ + slot * SLOT_ELEMS + pc * 512);
+            glds16_pipe(d_o + row * Dm + h * HD + sw, ringG + slot * SLOT_ELEMS + pc * 512);
+            glds16_pipe(o + row * Dm + h * HD + sw, ringO + oslot * SLOT_ELEMS + pc * 512);
+        }
+        glds4_pipe(lse + (int64_t)bh * N + min(q0 + (lane & 31), N - 1), ringLse + slot * 64);
+        if (DROP) {
+            // LDS row s of the slot holds query row rho(s): rows 4 apart (the four lane groups of a fragment) sit 8 words apart
+            const int s = lane >> 1, half = lane & 1;
+            const int rho = (s & 0x18) | ((s & 1) << 2) | ((s >> 1) & 3);
+            const uint32_t* src = drop_bits + ((int64_t)bh * N + min(q0 + rho, N - 1)) * 8 + 4 * half;
+            glds16_pipe(src, ringBits + slot * 256);
+        }
+    };
+    auto prod_aux = [&](int tp, int islot) {               // delta / scaled lse of step tp from its landed dO / O / lse pieces
+        int bh, q0;
+        step_head(tp, bh, q0);
+        const int slot = islot & (RING - 1), oslot = islot % ORING;
+        u32x4_t gv[4], ov[4];
+        float lraw;
+        // lane (r8, c8) holds chunk c8 of rows r8 + 8 k4, as in the lean kernel's prologue (same sums in the same order)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int r = r8 + 8 * k4;
+            const uint32_t off = (uint32_t)((r * HD + ((c8 ^ swz_dual(r)) << 3)) * 2);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(gv[k4]) : "v"(lds_addr32(ringG + slot * SLOT_ELEMS) + off));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ov[k4]) : "v"(lds_addr32(ringO + oslot * SLOT_ELEMS) + off));
+        }
+        asm volatile("ds_read_b32 %0, %1" : "=v"(lraw) : "v"(lds_addr32(ringLse + slot * 64 + (lane & 31))));
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(lraw)
+                     :
+                     : "memory");
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const bool live = q0 + r8 + 8 * k4 < N;
+            float d = live ? dot8_bf16(make_uint4(gv[k4][0], gv[k4][1], gv[k4][2], gv[k4][3]), make_uint4(ov[k4][0], ov[k4][1], ov[k4][2], ov[k4][3])) : 0.f;
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (c8 == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr32(ringDelta + slot * 32 + r8 + 8 * k4)), "v"(d) : "memory");
+        }
+        const float l2 = (q0 + lane < N) ? lraw * 1.44269504088896340736f : INFINITY;
+        if (lane < 32) asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr32(ringLse + slot * 64 + lane)), "v"(l2) : "memory");
+    };
+    if (wave == 15) {
+        prod_dma(0, 0);
+        prod_dma(min(1, T - 1), 1);
+        prod_dma(min(2, T - 1), 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 15) prod_aux(0, 0);
+    __syncthreads();
+
+    if (wave < NKT) {
+        // ================================================================ phase A: this wave's 16 keys, one 32-query block a step
+        const int t = wave;
+        const int key = 16 * t + i;
+        const int lq = i >> 2, lpp = i & 3;
+        int rowoff[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) rowoff[ks] = i * HD + (((4 * ks + g) ^ swz_dual(i)) << 3);
+        int troff[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) troff[dt] = (4 * g + lq) * HD + (((2 * dt + (lpp >> 1)) ^ swz_dual(4 * g + lq)) << 3) + 4 * (lpp & 1);
+        const int dst_w0 = dst_slot(key, 0, g), dst_w1 = dst_slot(key, 1, g);
+        const int bit_off = (8 * (g >> 1) + (g & 1)) * 8 + (i >> 2) * 2 + (t >> 3);       // + 128 qs + 16 r
+        const int bit_pos = 16 * (i & 1) + 8 * ((i >> 1) & 1) + (t & 7);
+        const uint32_t dsc_bits = __float_as_uint(drop_scale);
+        const float s0 = key < N ? 0.f : -INFINITY;
+        const float4_t sinit = (float4_t){s0, s0, s0, s0};
+        float4_t dk[4], dv[4];
+        bf16x8_t kfr[2], vfr[2];
+        int k = 0, j = 0;
+        for (int p = 0; p <= T; ++p) {
+            if (p < T) {
+                if (j == 0) {
+                    const bf16_t* Kc = Kimg + (k & 1) * NP * HD;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        kfr[ks] = lds_row_frag_dual(Kc, key, 4 * ks + g);
+                        vfr[ks] = lds_row_frag_dual(Vimg, key, 4 * ks + g);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        dk[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                        dv[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                const int slot = p & (RING - 1);
+                const int q0 = 32 * j;
+                const bf16_t* Qs = ringQ + slot * SLOT_ELEMS;
+                const bf16_t* Gs = ringG + slot * SLOT_ELEMS;
+                char* dSb = dST + (p & 1) * NP * 64;
+                const bool two = q0 + 16 < N;
+                float4_t pd[2], ds[2];
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    pd[qs] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    ds[qs] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                    if (qs == 0 || two) {
+                        const bf16_t* qrow = Qs + (16 * qs) * HD;
+                        const bf16_t* grow = Gs + (16 * qs) * HD;
+                        const float4_t l2 = *reinterpret_cast<const float4_t*>(ringLse + slot * 64 + 16 * qs + 4 * g);
+                        const float4_t dl = *reinterpret_cast<const float4_t*>(ringDelta + slot * 32 + 16 * qs + 4 * g);
+                        uint32_t bw[4] = {0u, 0u, 0u, 0u};
+                        if (DROP) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bw[r] = ringBits[slot * 256 + 128 * qs + 16 * r + bit_off];
+                        }
+                        float4_t sv = sinit, dp = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(qrow + rowoff[ks]), kfr[ks], sv, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(grow + rowoff[ks]), vfr[ks], dp, 0, 0, 0);
+                        }
+                        if (dbg_no_soft) {
+                            pd[qs] = sv;
+                            ds[qs] = dp;
+                        } else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], scale_log2, -l2[r]));
+                            float keepc = 1.0f;
+                            if (DROP) {
+                                const int32_t m = __builtin_amdgcn_sbfe((int32_t)bw[r], bit_pos, 1);
+                                keepc = __uint_as_float((uint32_t)m & dsc_bits);
+                            }
+                            pd[qs][r] = pr * keepc;
+                            ds[qs][r] = pr * __builtin_fmaf(dp[r], keepc, -dl[r]);
+                        }
+                    }
+                }
+                const bf16x8_t pf = pack8(pd[0], pd[1]);
+                const bf16x8_t sf = pack8(ds[0], ds[1]);
+                const int second = two ? 16 * HD : 0;
+                if (!dbg_no_acc)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8_t gt = lds_tr_frag_at(Gs + troff[dt], Gs + second + troff[dt]);
+                    const bf16x8_t qt = lds_tr_frag_at(Qs + troff[dt], Qs + second + troff[dt]);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sf, dk[dt], 0, 0, 0);
+                }
+                const uint4 sw = __builtin_bit_cast(uint4, sf);
+                *reinterpret_cast<uint2*>(dSb + dst_w0) = make_uint2(sw.x, sw.y);
+                *reinterpret_cast<uint2*>(dSb + dst_w1) = make_uint2(sw.z, sw.w);
+                if (j == NQB - 1 && key < N) {
+                    // the head is done for this key tile: dK^T / dV^T, lane (g,i) reg r = [d = 16dt + 4g + r][key]
+                    const int bh = (int)blockIdx.x + k * (int)gridDim.x;
+                    const int b = bh / H, h = bh - b * H;
+                    bf16_t* kp = dqkv + ((int64_t)b * N + key) * D3 + Dm + h * HD;
+                    bf16_t* vp = kp + Dm;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        uint2 w;
+                        w.x = pack_bf16x2(dk[dt][0] * scale, dk[dt][1] * scale);
+                        w.y = pack_bf16x2(dk[dt][2] * scale, dk[dt][3] * scale);
+                        *reinterpret_cast<uint2*>(kp + 16 * dt + 4 * g) = w;
+                        w.x = pack_bf16x2(dv[dt][0], dv[dt][1]);
+                        w.y = pack_bf16x2(dv[dt][2], dv[dt][3]);
+                        *reinterpret_cast<uint2*>(vp + 16 * dt + 4 * g) = w;
+                    }
+                }
+            }
+            if (dbg_period <= 1 || p % dbg_period == 0) lds_barrier();   // dbg_period > 1: timing experiment only (results WRONG)
+            if (++j == NQB) {
+                j = 0;
+                ++k;
+            }
+        }
+    } else if (wave < 15) {
+        // ================================================================ phase B (one step behind) + the next head's K / V pieces
+        const int widx = wave - NKT;
+        const int lq = i >> 2, lpp = i & 3;
+        const int kra = 8 * g + lq, krb = kra + 4;
+        int kboff[4][2], sboff[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            kboff[dt][0] = (kra * HD + (((2 * dt + (lpp >> 1)) ^ swz_dual(kra)) << 3) + 4 * (lpp & 1)) * 2;
+            kboff[dt][1] = (krb * HD + (((2 * dt + (lpp >> 1)) ^ swz_dual(krb)) << 3) + 4 * (lpp & 1)) * 2;
+        }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            sboff[qs][0] = dst_slot(kra, qs, lpp);
+            sboff[qs][1] = dst_slot(krb, qs, lpp);
+        }
+        int k = 0, j = 0, pk = 0, pj = 0;
+        for (int p = 0; p <= T; ++p) {
+            // the next head's K (wave 13) / V (wave 14) pieces go out at steps 1 .. 4 of a head, 7 a step (a piece costs its issuer
+            // 60 - 180 cycles: the producer alone was issue-bound); at the top of step 6 at least this wave's 8 dQ stores of steps 4
+            // and 5 (blocks 3 and 4 are full for N >= 193) have been issued behind the last piece, so "at most 4 outstanding" means
+            // every piece has landed - the barrier that ends step 6 publishes the images
+            if (p < T && j >= 1 && j <= 4 && k + 1 < nh && !dbg_no_prod) {
+                const int bhn = (int)blockIdx.x + (k + 1) * (int)gridDim.x;
+                const int first = 7 * (j - 1);
+                if (wave == 13) {
+                    bf16_t* img = Kimg + ((k + 1) & 1) * NP * HD;
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) kv_piece(bhn, 1, first + u, img);                            // 28 pieces
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) kv_piece(bhn, 2, min(first + u, NKT * 2 - 1), Vimg);          // 26 pieces (the last one three times)
+                }
+            }
+            if (p < T && j == NQB - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (p > 0 && !dbg_no_b) {
+                const int bh = (int)blockIdx.x + pk * (int)gridDim.x;
+                const int b = bh / H, h = bh - b * H;
+                const int qb0 = 32 * pj;
+                const char* dSb = dST + ((p - 1) & 1) * NP * 64;
+                const char* Kc = reinterpret_cast<const char*>(Kimg + (pk & 1) * NP * HD);
+                for (int task = widx; task < 8; task += 2) {
+                    const int qs = task >> 2, dtw = task & 3;
+                    if (qb0 + 16 * qs < N) {
+                        bf16x8_t kt[NTP], sb[NTP];
+                        const char* kp0 = Kc + (dtw == 0 ? kboff[0][0] : dtw == 1 ? kboff[1][0] : dtw == 2 ? kboff[2][0] : kboff[3][0]);
+                        const char* kp1 = Kc + (dtw == 0 ? kboff[0][1] : dtw == 1 ? kboff[1][1] : dtw == 2 ? kboff[2][1] : kboff[3][1]);
+                        const char* sp0 = dSb + (qs ? sboff[1][0] : sboff[0][0]);
+                        const char* sp1 = dSb + (qs ? sboff[1][1] : sboff[0][1]);
+#pragma unroll
+                        for (int u = 0; u < NTP; ++u) {
+                            kt[u] = lds_tr_frag_at(reinterpret_cast<const bf16_t*>(kp0 + u * 32 * HD * 2), reinterpret_cast<const bf16_t*>(kp1 + u * 32 * HD * 2));
+                            sb[u] = lds_tr_frag_at(reinterpret_cast<const bf16_t*>(sp0 + u * 32 * 64), reinterpret_cast<const bf16_t*>(sp1 + u * 32 * 64));
+                        }
+                        float4_t dq = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int u = 0; u < NTP; ++u) dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[u], sb[u], dq, 0, 0, 0);
+                        const int q = qb0 + 16 * qs + i;
+                        if (q < N) {
+                            uint2 w;
+                            w.x = pack_bf16x2(dq[0] * scale, dq[1] * scale);
+                            w.y = pack_bf16x2(dq[2] * scale, dq[3] * scale);
+                            *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * dtw + 4 * g) = w;
+                        }
+                    }
+                }
+            }
+            if (dbg_period <= 1 || p % dbg_period == 0) lds_barrier();   // dbg_period > 1: timing experiment only (results WRONG)
+            pk = k;
+            pj = j;
+            if (++j == NQB) {
+                j = 0;
+                ++k;
+            }
+        }
+    } else {
+        // ================================================================ producer
+        // Iteration p, between the barriers that end steps p - 1 and p:
+        //   1. wait until at most the NDMA pieces issued in iteration p - 1 are outstanding (a wave's loads, stores and LDS-DMA retire
+        //      in issue order): everything issued in iteration p - 2 or earlier has landed - the ring pieces of step p + 1;
+        //   2. delta / scaled lse of step p + 1 from the landed pieces (published, like the pieces, by the barrier that ends step p);
+        //   3. issue the ring pieces of step p + 3 (into the slots step p - 1 has just released).
+        for (int p = 0; p <= T; ++p) {
+            if (p < T && !dbg_no_prod) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                if (p + 1 < T) prod_aux(p + 1, p + 1);
+                prod_dma(min(p + 3, T - 1), p + 3);
+            }
+            if (dbg_period <= 1 || p % dbg_period == 0) lds_barrier();   // dbg_period > 1: timing experiment only (results WRONG)
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ forward, long sequences
 // N > 224: the score row of a query no longer fits the register file next to K/V in LDS.  Workgroup = (head, 128
 // queries), a wave owns 16 queries; K / V stream through a double-buffered LDS chunk of 64 keys and the softmax is
@@ -1506,8 +1885,32 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
         CHB_LAUNCH_CHECK();
         return CHB_OK;
     }
-    // default (no fused bias gradient, CHB_ATTN_BWD_ALGO = 0): the lean kernel; it tests the forward's keep bits when they are given
-    if (!dbias_qkv && (bwd_algo == 0 || bwd_algo == 4)) {
+    // 193 <= N <= 208 (ViT at 224^2: 197 / 198 tokens), no fused bias gradient, dropout through the forward's keep bits or none: the
+    // persistent pipelined kernel, one workgroup per CU (CHB_ATTN_BWD_ALGO = 4 keeps the lean one-workgroup-per-head kernel for A/B)
+    if (!dbias_qkv && (bwd_algo == 0 || bwd_algo == 5) && N >= 193 && N <= 16 * pipe::NKT && (!thr || drop_bits)) {
+        static std::atomic<int> n_cus[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CHB_ELAUNCH;
+        int cus = n_cus[dev].load(std::memory_order_acquire);
+        if (cus == 0) {
+            // first launch on this device: CU count, and the kernels' dynamic LDS limit (both per device)
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return CHB_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe::LDS_BYTES) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe::LDS_BYTES) != hipSuccess)
+                return CHB_ELAUNCH;
+            n_cus[dev].store(cus, std::memory_order_release);
+        }
+        const int total = B * H;
+        const dim3 pgrid(total < cus ? total : cus);
+        if (thr) hipLaunchKernelGGL((attn_bwd_pipe_kernel<true>), pgrid, dim3(1024), pipe::LDS_BYTES, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse,
+                                    (bf16_t*)dqkv, drop_bits, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
+        else hipLaunchKernelGGL((attn_bwd_pipe_kernel<false>), pgrid, dim3(1024), pipe::LDS_BYTES, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse,
+                                (bf16_t*)dqkv, drop_bits, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
+    // otherwise (no fused bias gradient): the lean kernel; it tests the forward's keep bits when they are given
+    if (!dbias_qkv && (bwd_algo == 0 || bwd_algo == 4 || bwd_algo == 5)) {
 #define CHB_BWDH_V(NTP, DROP, BITS)                                                                                              \
     do {                                                                                                                         \
         const size_t lds = bwd_head_lds_bytes<NTP>();                                                                            \
