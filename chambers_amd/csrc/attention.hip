@@ -998,9 +998,19 @@ __device__ __forceinline__ void glds16_pipe(const void* src, const void* lds_wav
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");   // m0 is reserved (not allocatable): the asm owns it, see the note above
 }
 
-__device__ __forceinline__ void glds4_pipe(const void* src, const void* lds_wave_base) {      // 64 lanes x 4 bytes
+// the same with a wave-uniform base in scalar registers and a 32-bit byte offset per lane: no 64-bit vector arithmetic per piece (the
+// producer wave's address chains were a third of its issue time)
+__device__ __forceinline__ uint64_t uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+__device__ __forceinline__ void glds16_pipe_s(const void* sbase, uint32_t voff, const void* lds_wave_base) {
     const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_addr32(lds_wave_base));
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "memory");   // m0 is reserved (not allocatable): the asm owns it, see the note above
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(uniform_ptr(sbase)), "s"(m0v) : "memory");
+}
+__device__ __forceinline__ void glds4_pipe_s(const void* sbase, uint32_t voff, const void* lds_wave_base) {      // 64 lanes x 4 bytes
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_addr32(lds_wave_base));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(uniform_ptr(sbase)), "s"(m0v) : "memory");
 }
 
 namespace pipe {
@@ -1052,8 +1062,9 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
     auto kv_piece = [&](int bh, int which, int inst, bf16_t* img) {
         const int b = bh / H, h = bh - b * H;
         const int r = inst * 8 + r8;
-        const bf16_t* src = qkv + ((int64_t)b * N + min(r, N - 1)) * D3 + (int64_t)which * Dm + h * HD + ((c8 ^ swz_dual(r)) << 3);
-        glds16_pipe(src, img + inst * 512);
+        const bf16_t* sbase = qkv + (int64_t)b * N * D3 + (int64_t)which * Dm + h * HD;
+        const uint32_t voff = (__umul24((uint32_t)min(r, N - 1), (uint32_t)(3 * Dm)) + (uint32_t)((c8 ^ swz_dual(r)) << 3)) * 2u;
+        glds16_pipe_s(sbase, voff, img + inst * 512);
     };
 
     // ---- prologue: zero dS^T (rows of dead key tiles stay zero for good), first head's K / V, the producer's first three steps
@@ -1077,22 +1088,26 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
         step_head(tp, bh, q0);
         const int b = bh / H, h = bh - b * H;
         const int slot = islot & (RING - 1), oslot = islot % ORING;
+        const int rmax = N - 1 - q0;                       // rows past the last token re-read it (only a head's last block has any)
+        const int64_t tok = (int64_t)b * N + q0;
+        const bf16_t* qb = qkv + tok * D3 + h * HD;
+        const bf16_t* gb = d_o + tok * Dm + h * HD;
+        const bf16_t* ob = o + tok * Dm + h * HD;
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) {
             const int r = 8 * pc + r8;
-            const int64_t row = (int64_t)b * N + min(q0 + r, N - 1);
-            const int sw = (c8 ^ swz_dual(r)) << 3;
-            glds16_pipe(qkv + row * D3 + h * HD + sw, ringQ + slot * SLOT_ELEMS + pc * 512);
-            glds16_pipe(d_o + row * Dm + h * HD + sw, ringG + slot * SLOT_ELEMS + pc * 512);
-            glds16_pipe(o + row * Dm + h * HD + sw, ringO + oslot * SLOT_ELEMS + pc * 512);
+            const uint32_t t = __umul24((uint32_t)min(r, rmax), (uint32_t)Dm);
+            const uint32_t sw = (uint32_t)((c8 ^ swz_dual(r)) << 3);
+            glds16_pipe_s(qb, (3u * t + sw) * 2u, ringQ + slot * SLOT_ELEMS + pc * 512);
+            glds16_pipe_s(gb, (t + sw) * 2u, ringG + slot * SLOT_ELEMS + pc * 512);
+            glds16_pipe_s(ob, (t + sw) * 2u, ringO + oslot * SLOT_ELEMS + pc * 512);
         }
-        glds4_pipe(lse + (int64_t)bh * N + min(q0 + (lane & 31), N - 1), ringLse + slot * 64);
+        glds4_pipe_s(lse + (int64_t)bh * N + q0, (uint32_t)min(lane & 31, rmax) * 4u, ringLse + slot * 64);
         if (DROP) {
             // LDS row s of the slot holds query row rho(s): rows 4 apart (the four lane groups of a fragment) sit 8 words apart
             const int s = lane >> 1, half = lane & 1;
             const int rho = (s & 0x18) | ((s & 1) << 2) | ((s >> 1) & 3);
-            const uint32_t* src = drop_bits + ((int64_t)bh * N + min(q0 + rho, N - 1)) * 8 + 4 * half;
-            glds16_pipe(src, ringBits + slot * 256);
+            glds16_pipe_s(drop_bits + ((int64_t)bh * N + q0) * 8, (uint32_t)(min(rho, rmax) * 8 + 4 * half) * 4u, ringBits + slot * 256);
         }
     };
     auto prod_aux = [&](int tp, int islot) {               // delta / scaled lse of step tp from its landed dO / O / lse pieces
@@ -1118,9 +1133,12 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
         for (int k4 = 0; k4 < 4; ++k4) {
             const bool live = q0 + r8 + 8 * k4 < N;
             float d = live ? dot8_bf16(make_uint4(gv[k4][0], gv[k4][1], gv[k4][2], gv[k4][3]), make_uint4(ov[k4][0], ov[k4][1], ov[k4][2], ov[k4][3])) : 0.f;
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
+            // the 8 lanes of a row: lane ^ 1, lane ^ 2 (quad permutes), then the mirrored lane of the 8-group (it sits in the other quad,
+            // whose four lanes all hold that quad's sum): the same three additions as __shfl_xor 1 / 2 / 4, as DPP moves instead of
+            // ds_bpermute round trips (12 dependent LDS-crossbar trips an iteration were a third of the producer's time)
+            d += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, true));
+            d += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, true));
+            d += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d), 0x141, 0xF, 0xF, true));
             if (c8 == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr32(ringDelta + slot * 32 + r8 + 8 * k4)), "v"(d) : "memory");
         }
         const float l2 = (q0 + lane < N) ? lraw * 1.44269504088896340736f : INFINITY;
@@ -1270,6 +1288,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
             sboff[qs][1] = dst_slot(krb, qs, lpp);
         }
         int k = 0, j = 0, pk = 0, pj = 0;
+        bf16x8_t kt[2][NTP];
         for (int p = 0; p <= T; ++p) {
             // the next head's K (wave 13) / V (wave 14) pieces go out at steps 1 .. 4 of a head, 7 a step (a piece costs its issuer
             // 60 - 180 cycles: the producer alone was issue-bound); at the top of step 6 at least this wave's 8 dQ stores of steps 4
@@ -1293,29 +1312,46 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
                 const int b = bh / H, h = bh - b * H;
                 const int qb0 = 32 * pj;
                 const char* dSb = dST + ((p - 1) & 1) * NP * 64;
-                const char* Kc = reinterpret_cast<const char*>(Kimg + (pk & 1) * NP * HD);
-                for (int task = widx; task < 8; task += 2) {
-                    const int qs = task >> 2, dtw = task & 3;
-                    if (qb0 + 16 * qs < N) {
-                        bf16x8_t kt[NTP], sb[NTP];
-                        const char* kp0 = Kc + (dtw == 0 ? kboff[0][0] : dtw == 1 ? kboff[1][0] : dtw == 2 ? kboff[2][0] : kboff[3][0]);
-                        const char* kp1 = Kc + (dtw == 0 ? kboff[0][1] : dtw == 1 ? kboff[1][1] : dtw == 2 ? kboff[2][1] : kboff[3][1]);
-                        const char* sp0 = dSb + (qs ? sboff[1][0] : sboff[0][0]);
-                        const char* sp1 = dSb + (qs ? sboff[1][1] : sboff[0][1]);
+                if (pj == 0) {
+                    // first block of a head: this wave's K^T fragments (A[row d][k = key 32u + 8g + j], d tiles widx and widx + 2) stay in
+                    // registers for the head's seven blocks - the lean kernel re-read them from the K image for every task
+                    const char* Kc = reinterpret_cast<const char*>(Kimg + (pk & 1) * NP * HD);
+#pragma unroll
+                    for (int dd = 0; dd < 2; ++dd) {
+                        const char* kp0 = Kc + (widx ? kboff[2 * dd + 1][0] : kboff[2 * dd][0]);
+                        const char* kp1 = Kc + (widx ? kboff[2 * dd + 1][1] : kboff[2 * dd][1]);
+#pragma unroll
+                        for (int u = 0; u < NTP; ++u)
+                            kt[dd][u] = lds_tr_frag_at(reinterpret_cast<const bf16_t*>(kp0 + u * 32 * HD * 2), reinterpret_cast<const bf16_t*>(kp1 + u * 32 * HD * 2));
+                    }
+                }
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    if (qb0 + 16 * qs < N) {   // wave-uniform
+                        // B[k = key][col = query] = dS^T, shared by the wave's two d tiles; the two MFMA chains are independent
+                        bf16x8_t sb[NTP];
+                        const char* sp0 = dSb + sboff[qs][0];
+                        const char* sp1 = dSb + sboff[qs][1];
+#pragma unroll
+                        for (int u = 0; u < NTP; ++u)
+                            sb[u] = lds_tr_frag_at(reinterpret_cast<const bf16_t*>(sp0 + u * 32 * 64), reinterpret_cast<const bf16_t*>(sp1 + u * 32 * 64));
+                        float4_t dq0 = (float4_t){0.f, 0.f, 0.f, 0.f}, dq1 = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int u = 0; u < NTP; ++u) {
-                            kt[u] = lds_tr_frag_at(reinterpret_cast<const bf16_t*>(kp0 + u * 32 * HD * 2), reinterpret_cast<const bf16_t*>(kp1 + u * 32 * HD * 2));
-                            sb[u] = lds_tr_frag_at(reinterpret_cast<const bf16_t*>(sp0 + u * 32 * 64), reinterpret_cast<const bf16_t*>(sp1 + u * 32 * 64));
+                            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[0][u], sb[u], dq0, 0, 0, 0);
+                            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[1][u], sb[u], dq1, 0, 0, 0);
                         }
-                        float4_t dq = (float4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int u = 0; u < NTP; ++u) dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[u], sb[u], dq, 0, 0, 0);
+                        // D[row = d 4g+r][col = query i]
                         const int q = qb0 + 16 * qs + i;
                         if (q < N) {
+                            bf16_t* dst = dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * widx + 4 * g;
                             uint2 w;
-                            w.x = pack_bf16x2(dq[0] * scale, dq[1] * scale);
-                            w.y = pack_bf16x2(dq[2] * scale, dq[3] * scale);
-                            *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * N + q) * D3 + h * HD + 16 * dtw + 4 * g) = w;
+                            w.x = pack_bf16x2(dq0[0] * scale, dq0[1] * scale);
+                            w.y = pack_bf16x2(dq0[2] * scale, dq0[3] * scale);
+                            *reinterpret_cast<uint2*>(dst) = w;
+                            w.x = pack_bf16x2(dq1[0] * scale, dq1[1] * scale);
+                            w.y = pack_bf16x2(dq1[2] * scale, dq1[3] * scale);
+                            *reinterpret_cast<uint2*>(dst + 32) = w;
                         }
                     }
                 }

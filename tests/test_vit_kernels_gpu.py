@@ -610,6 +610,36 @@ def test_attention_fwd_bwd(bsz, n, h, rate, variant):
         assert r < 1e-2, "%s rel-l2 %g" % (name, r)
 
 
+@pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.0), (2, 197, 3, 0.1), (1, 193, 1, 0.1), (3, 198, 2, 0.1), (2, 208, 2, 0.25), (1, 208, 1, 0.0),
+                                          # more heads than CUs: some workgroups of the persistent kernel walk two heads (head boundaries inside the stream of steps)
+                                          (23, 197, 12, 0.1), (23, 197, 12, 0.0), (45, 200, 13, 0.1)])
+def test_attention_bwd_pipelined_is_bit_identical_to_lean(bsz, n, h, rate):
+    """193 <= N <= 208 runs the persistent pipelined backward (attn_bwd_pipe_kernel: one workgroup per CU, Q / dO / O / keep-bit rings
+    by LDS-DMA, a producer wave, the next head's K / V prefetched) - the same MFMA products and sums in the same order as the lean
+    one-workgroup-per-head kernel (CHB_ATTN_BWD_ALGO = 4), so dQ, dK and dV agree bit for bit."""
+    from chambers_amd import _lib, kernels as K
+    d = h * 64
+    key = 0x2468ace
+    qkv = bf(torch.randn(bsz * n, 3 * d, generator=g(46))).cuda()
+    do = bf(torch.randn(bsz * n, d, generator=g(47))).cuda()
+    o = torch.empty(bsz * n, d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(bsz * h * n, dtype=torch.float32, device="cuda")
+    bits = K.attention_drop_bits(bsz, n, h) if rate else None
+    K.attention_fwd(qkv, o, lse, bsz, n, h, 64, rate, key, drop_bits=bits)
+    outs = []
+    try:
+        for algo in (4, 0):
+            _lib.set_option("ATTN_BWD_ALGO", algo)
+            dqkv = torch.full((bsz * n, 3 * d), float("nan"), dtype=torch.bfloat16, device="cuda")
+            K.attention_bwd(qkv, o, do, lse, dqkv, bsz, n, h, 64, rate, key, drop_bits=bits)
+            torch.cuda.synchronize()
+            outs.append(dqkv.view(torch.int16).cpu())
+    finally:
+        _lib.set_option("ATTN_BWD_ALGO", 0)
+    assert not torch.isnan(outs[1].view(torch.bfloat16).float()).any()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.1), (1, 224, 2, 0.0), (3, 50, 1, 0.1), (1, 1, 1, 0.0), (2, 130, 2, 0.5)])
 def test_attention_bwd_two_pass_matches_one_pass(bsz, n, h, rate, monkeypatch):
     """The long-sequence backward (N > 224) forced onto short inputs agrees with the LDS-resident one: dK / dV accumulate
