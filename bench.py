@@ -42,57 +42,38 @@ def forward_flops_per_image(cfg):
 
 
 class KernelTimer:
-    """HIP-event bracket around selected launches (events are recorded on the stream the kernels run on)."""
+    """The library's launch profiler (chb_profile_enable / chb_profile_collect, include/chambers_hip.h): HIP events recorded by
+    chb_gemm_nt / chb_gemm_tn_ws themselves, on the stream each GEMM is launched on, right before and right after the launch - also
+    when the launch comes from inside a block-level call (chb_vit_block_fwd / _bwd), where no Python code runs between two GEMMs."""
+
+    NT = {1: "gemm_nt_kernel", 2: "gemm_nt256_kernel", 3: "gemm_nt128_kernel", 4: "gemm_nt256pp_kernel", 5: "gemm_nt256sp_kernel"}
+    TN = {0: "gemm_tn_kernel", 1: "gemm_tn256_kernel"}
 
     def __init__(self):
-        self.records = []   # (name, work, start_event, stop_event)
+        self.records = []   # (name, work, start_ms, ms)
         self.enabled = False
 
-    def nt256_name(self, m, n):
-        algo = int(os.environ.get("CHB_GEMM_ALGO", "0"))
-        if algo == 0:       # csrc/gemm.hip launch_nt(): the pipelined kernel where every tile is full, the lockstep one on ragged shapes
-            algo = 5 if (m % 256 == 0 and n % 256 == 0) else 2
-        return {5: "gemm_nt256sp_kernel", 4: "gemm_nt256pp_kernel"}.get(algo, "gemm_nt256_kernel")
+    def start(self):
+        from chambers_amd import _lib
+        _lib.profile_enable(True)
+        self.enabled = True
 
-    def wrap(self, K):
-        timer = self
-        orig_nt, orig_tn = K.gemm_nt, K.gemm_tn
-
-        def gemm_nt(a, b, out, m=None, **kw):
-            if not timer.enabled:
-                return orig_nt(a, b, out, m=m, **kw)
-            mm = a.shape[0] if m is None else m
-            # same selection rule as csrc/gemm.hip launch_nt(): persistent 256x256 tiles for large problems - the pipelined kernel
-            # (gemm_nt256sp_kernel) unless CHB_GEMM_ALGO asks for another schedule
-            fam = timer.nt256_name(mm, b.shape[0]) if (mm >= 2048 and b.shape[0] >= 256) else "gemm_nt_kernel"
-            name = "%s<%d, %d>" % (fam, kw.get("epilogue", 0), 1 if out.dtype == torch.float32 else 0)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_nt(a, b, out, m=m, **kw)
-            e.record()
-            timer.records.append((name, 2.0 * mm * b.shape[0] * b.shape[1], s, e))
-            return r
-
-        def gemm_tn(x, dy, dw, m=None, ws=None, fold=True, colsum=None):
-            if not timer.enabled:
-                return orig_tn(x, dy, dw, m=m, ws=ws, fold=fold, colsum=colsum)
-            mm = x.shape[0] if m is None else m
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_tn(x, dy, dw, m=m, ws=ws, fold=False, colsum=colsum)      # the GEMM launch alone sits between the events ...
-            e.record()
-            if fold:
-                K.gemm_tn_fold(x, dy, dw, m=m, ws=ws)           # ... the fold of its partial planes (tn_reduce_kernel) follows
-            fam = "gemm_tn256_kernel" if (mm >= 4096 and x.shape[1] >= 128 and dy.shape[1] >= 128) else "gemm_tn_kernel"
-            timer.records.append((fam, 2.0 * mm * x.shape[1] * dy.shape[1], s, e))
-            return r
-
-        K.gemm_nt, K.gemm_tn = gemm_nt, gemm_tn
+    def stop(self):
+        """Call after the device has been synchronised."""
+        from chambers_amd import _lib
+        _lib.profile_enable(False)
+        self.enabled = False
+        self.records = []
+        for r in _lib.profile_collect():
+            if r["kind"] == 0:
+                name = "%s<%d, %d>" % (self.NT.get(r["family"], "gemm_nt?"), r["epilogue"], r["out_dtype"])
+            else:
+                name = self.TN.get(r["family"], "gemm_tn?")
+            self.records.append((name, 2.0 * r["m"] * r["n"] * r["k"], r["start_ms"], r["ms"]))
 
     def summary(self):
         agg = {}
-        for name, work, s, e in self.records:
-            ms = s.elapsed_time(e)
+        for name, work, _t0, ms in self.records:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += ms
@@ -105,8 +86,7 @@ class KernelTimer:
         weight-gradient GEMMs beside the dgrad chain), so the sum of durations counts shared time twice."""
         if not self.records:
             return 0.0
-        base = self.records[0][2]
-        iv = sorted((base.elapsed_time(s), base.elapsed_time(e)) for _n, _w, s, e in self.records)
+        iv = sorted((t0, t0 + ms) for _n, _w, t0, ms in self.records)
         total, cur_a, cur_b = 0.0, iv[0][0], iv[0][1]
         for a, b in iv[1:]:
             if a > cur_b:
@@ -395,7 +375,6 @@ def main():
     from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
 
     timer = KernelTimer()
-    timer.wrap(K)
 
     cfg_kwargs = dict(MODELS[args.model], dropout_rate=0.1, image_size=(args.image_size, args.image_size), classes=1000)
     cfg = ViTConfig(**cfg_kwargs)
@@ -454,7 +433,7 @@ def main():
     red = eng.reducer
     red.measure = True
     red.n_collectives = red.bytes_reduced = 0
-    timer.enabled = True
+    timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -464,7 +443,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    timer.stop()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -475,7 +454,6 @@ def main():
     # difference to the timed region above is what the exchange costs a step, waits and CU contention included
     ms_no_exchange = None
     if dist is not None:
-        timer.enabled = False
         red.measure = False
         red.active = False
         step()

@@ -24,6 +24,7 @@ SOURCES = {
     "attention_general.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "metric.hip": [],
+    "vit_block.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
           "-munsafe-fp-atomics"]

@@ -92,8 +92,50 @@ PROTOTYPES = {
     "chb_dropout_f32": [P, P, c_int64, c_float, ctypes.c_uint32, P],
     "chb_add_rows_f32": [P, P, P, c_int64, c_int64, P],
     "chb_sum_rows_f32": [P, c_int64, c_int64, c_int64, P, P],
+    "chb_vit_block_fwd": [P, c_int, P],
+    "chb_vit_block_bwd": [P, c_int, P, P],
+    "chb_side_stream_join": [P, P],
+    "chb_profile_enable": [c_int],
+    "chb_profile_collect": [P, c_int, P],
 }
 INFO_SYMBOLS = ["chb_version", "chb_build_arch"]
+
+c_int32 = ctypes.c_int32
+
+
+class VitBlock(ctypes.Structure):
+    """`chb_vit_block` of include/chambers_hip.h, field for field (tests/test_abi_signatures.py compares the two declarations and the
+    byte layout a C compiler gives the header's struct)."""
+    _fields_ = ([(n, c_int32) for n in ("B", "N", "H", "hd", "D", "FF", "M", "Mg", "Mp")] +
+                [("eps", c_float), ("drop_rate", c_float)] +
+                [(n, c_uint32) for n in ("key_attn", "key_proj", "key_mlp", "key_prev_mlp")] +
+                [("emit_dz", c_int32), ("reserved", c_int32)] +
+                [(n, P) for n in ("ln1_gamma", "ln1_beta", "ln2_gamma", "ln2_beta", "qkv_bias", "proj_bias", "fc1_bias", "fc2_bias",
+                                  "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt", "qkv_w", "proj_w", "fc1_w", "fc2_w", "x_in", "x_out",
+                                  "h1", "qkv", "o", "h2", "a1", "u", "mean1", "rstd1", "lse", "xmid", "mean2", "rstd2", "drop_bits",
+                                  "g_ln1_gamma", "g_ln1_beta", "g_ln2_gamma", "g_ln2_beta", "g_qkv_bias", "g_proj_bias", "g_fc1_bias",
+                                  "g_prev_fc2_bias", "g_qkv_w", "g_proj_w", "g_fc1_w", "g_fc2_w", "dx", "dz", "da1", "dh", "d_o", "dqkv",
+                                  "tn_ws", "tn_ws_side")] +
+                [("tn_ws_bytes", c_int64)])
+
+
+class ProfileRecord(ctypes.Structure):
+    """`chb_profile_record` of include/chambers_hip.h."""
+    _fields_ = [("kind", c_int32), ("family", c_int32), ("epilogue", c_int32), ("out_dtype", c_int32), ("m", c_int64), ("n", c_int64),
+                ("k", c_int64), ("ms", c_float), ("start_ms", c_float)]
+
+
+def profile_enable(on):
+    call("chb_profile_enable", 1 if on else 0)
+
+
+def profile_collect():
+    """Records of the current profiling period as a list of dicts (waits for the recorded events)."""
+    n = ctypes.c_int(0)
+    call("chb_profile_collect", None, 0, ctypes.byref(n))
+    recs = (ProfileRecord * max(n.value, 1))()
+    call("chb_profile_collect", ctypes.cast(recs, c_void_p), n.value, ctypes.byref(n))
+    return [{f: getattr(recs[i], f) for f, _t in ProfileRecord._fields_} for i in range(n.value)]
 
 _lib = None
 

@@ -121,3 +121,7 @@ enum ChbOption {
     CHB_OPT_COUNT
 };
 int chb_option(int id);   // defined in elementwise.hip
+
+// ---- launch profiler (csrc/vit_block.hip; chb_profile_enable / chb_profile_collect in the header): a slot, or -1 when recording is off
+int chb_prof_begin(int kind, int epi, int out_dtype, int64_t m, int64_t n, int64_t k, hipStream_t s);
+void chb_prof_end(int slot, int family, hipStream_t s);

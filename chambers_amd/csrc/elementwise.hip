@@ -440,7 +440,7 @@ int chb_set_option(const char* name, int value) {
     return CHB_EINVAL;
 }
 
-int chb_version(void) { return 3; }
+int chb_version(void) { return 4; }
 const char* chb_build_arch(void) { return "gfx950"; }
 
 int chb_dropout_mask(uint8_t* out, int64_t n, float rate, uint32_t key, void* stream) {

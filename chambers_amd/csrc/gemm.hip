@@ -2201,6 +2201,7 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
         p.queue_slot = chb_option(CHB_OPT_GEMM_TILE_QUEUE) ? (int)(launch_seq.fetch_add(1, std::memory_order_relaxed) % TILE_QUEUE_SLOTS) : -1;
     }
     hipStream_t s = (hipStream_t)stream;
+    const int prof = chb_prof_begin(0, epilogue, out_dtype, M, N, K, s);
     switch (epilogue) {
         int rc;
         case CHB_EPI_NONE: rc = launch_nt<CHB_EPI_NONE>(p, out_dtype, s); if (rc) return rc; break;
@@ -2209,6 +2210,13 @@ int chb_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
         case CHB_EPI_RESID: rc = launch_nt<CHB_EPI_RESID>(p, out_dtype, s); if (rc) return rc; break;
         case CHB_EPI_PATCH: rc = launch_nt<CHB_EPI_PATCH>(p, out_dtype, s); if (rc) return rc; break;
         default: return CHB_EINVAL;
+    }
+    if (prof >= 0) {      // which kernel launch_nt picked (same rule)
+        int algo = gemm_algo_override();
+        const bool full_tiles = !(M & 255) && !(N & 255) && (out_dtype == CHB_OUT_F32 || (!(ldc & 7) && !(aux && (ld_aux & 7))));
+        if (algo == 0) algo = (M >= 2048 && N >= 256) ? (full_tiles ? 5 : 2) : 1;
+        if (algo == 4 && ((M & 255) || (N & 255) || K < 4 * BK || (ldc & 7) || (aux && (ld_aux & 7)))) algo = 2;
+        chb_prof_end(prof, algo, s);
     }
     CHB_LAUNCH_CHECK();
     return CHB_OK;
@@ -2276,6 +2284,7 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
             const dim3 grid(pl.tiles_k * pl.tiles_n * q.splits);
             const bool fast = !(Kd & 255) && !(Nd & 255) && chb_option(CHB_OPT_TN_FAST) != 0;   // 0 = generic staging addresses (A/B timing)
             hipStream_t st = (hipStream_t)stream;
+            const int prof = chb_prof_begin(1, dy_colsum ? 1 : 0, CHB_OUT_F32, Kd, Nd, M, st);
             if (dy_colsum) {
                 if (fast) hipLaunchKernelGGL((gemm_tn256_kernel<true, true>), grid, dim3(512), 0, st, q);
                 else hipLaunchKernelGGL((gemm_tn256_kernel<true, false>), grid, dim3(512), 0, st, q);
@@ -2283,6 +2292,7 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
                 if (fast) hipLaunchKernelGGL((gemm_tn256_kernel<false, true>), grid, dim3(512), 0, st, q);
                 else hipLaunchKernelGGL((gemm_tn256_kernel<false, false>), grid, dim3(512), 0, st, q);
             }
+            chb_prof_end(prof, 1, st);
             CHB_LAUNCH_CHECK();
             if (pl.planes && fold) return chb_gemm_tn_fold(workspace, workspace_bytes, dW, ldw, M, Kd, Nd, stream);
             return CHB_OK;
@@ -2299,7 +2309,9 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
     if (splits < 1) splits = 1;
     p.steps_per_split = chb_div_up(steps, splits);
     p.splits = chb_div_up(steps, p.steps_per_split);
+    const int prof = chb_prof_begin(1, dy_colsum ? 1 : 0, CHB_OUT_F32, Kd, Nd, M, (hipStream_t)stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * p.splits), dim3(256), 0, (hipStream_t)stream, p);
+    chb_prof_end(prof, 0, (hipStream_t)stream);
     CHB_LAUNCH_CHECK();
     if (dy_colsum) return chb_colsum_bf16(dY, ldy, dy_colsum, M, Nd, stream);     // small shapes: the stand-alone pass
     return CHB_OK;

@@ -18,6 +18,7 @@ embeddings) so that data-parallel buckets are contiguous slices that can be all-
 earlier blocks are still in backward.  Two bf16 images of the matrices are refreshed after every
 optimizer step: [K][N] (B operand of dgrad) and its transpose [N][K] (B operand of forward).
 """
+import ctypes
 import math
 import os
 
@@ -641,6 +642,47 @@ class ViTEngine:
                 self.dqkv_ring = _SideRing([self.dqkv, z(Mp, 3 * d)])
             self.dpatch = z(self.Mpatch_p, d)
             self.labels = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        # One C-ABI call per encoder block and direction (chb_vit_block_fwd / _bwd: the same launches in the same order, issued from
+        # C): the records are filled once - every buffer is static - and only the dropout keys (and, at inference, the ping-pong
+        # x_in / x_out) change per call.  CHB_ENGINE_PY_BLOCKS=1 keeps the launch-by-launch Python path (tests compare the two).
+        self.c_blocks = not bool(int(os.environ.get("CHB_ENGINE_PY_BLOCKS", "0")))
+        self._build_block_records()
+
+    def _build_block_records(self):
+        cfg = self.cfg
+        L, d = cfg.n_encoder_layers, cfg.patch_dim
+        dp = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        self.blocks = []
+        for l in range(L):
+            pre = "encoder/layer_%d/" % l
+            a = self.acts[l if self.training else 0]
+            r = _lib.VitBlock()
+            r.B, r.N, r.H, r.hd, r.D, r.FF = self.B, cfg.n_tokens, cfg.n_heads, cfg.head_dim, d, cfg.ff_dim
+            r.M, r.Mg, r.Mp = self.M, self.Mg, self.Mp
+            r.eps, r.drop_rate = cfg.norm_epsilon, cfg.dropout_rate
+            r.emit_dz = 1 if l > 0 else 0
+            for f, n in (("ln1_gamma", "norm1/gamma"), ("ln1_beta", "norm1/beta"), ("ln2_gamma", "norm2/gamma"), ("ln2_beta", "norm2/beta"),
+                         ("qkv_bias", "qkv/bias"), ("proj_bias", "proj/bias"), ("fc1_bias", "dense1/bias"), ("fc2_bias", "dense2/bias")):
+                setattr(r, f, dp(self.p(pre + n)))
+            for f, n in (("qkv", "qkv/kernel"), ("proj", "proj/kernel"), ("fc1", "dense1/kernel"), ("fc2", "dense2/kernel")):
+                setattr(r, f + "_wt", dp(self.wbt(pre + n)))
+                setattr(r, f + "_w", dp(self.wb(pre + n)))
+            for f in ("h1", "qkv", "o", "h2", "a1", "u", "mean1", "rstd1", "lse", "xmid", "mean2", "rstd2", "drop_bits"):
+                setattr(r, f, dp(a[f]))
+            if self.training:
+                r.x_in, r.x_out = dp(self.xs[l]), dp(self.xs[l + 1])
+                for f, n in (("g_ln1_gamma", "norm1/gamma"), ("g_ln1_beta", "norm1/beta"), ("g_ln2_gamma", "norm2/gamma"), ("g_ln2_beta", "norm2/beta"),
+                             ("g_qkv_bias", "qkv/bias"), ("g_proj_bias", "proj/bias"), ("g_fc1_bias", "dense1/bias"), ("g_qkv_w", "qkv/kernel"),
+                             ("g_proj_w", "proj/kernel"), ("g_fc1_w", "dense1/kernel"), ("g_fc2_w", "dense2/kernel")):
+                    setattr(r, f, dp(self.g(pre + n)))
+                if l > 0:
+                    r.g_prev_fc2_bias = dp(self.g("encoder/layer_%d/dense2/bias" % (l - 1)))
+                for f in ("dx", "dz", "da1", "dh", "dqkv"):
+                    setattr(r, f, dp(getattr(self, f)))
+                r.d_o = dp(self.do)
+                r.tn_ws, r.tn_ws_bytes = dp(self.tn_ws), self.tn_ws.numel() * 4
+                r.tn_ws_side = dp(self.tn_ws_side) if self.overlap_wgrad else None
+            self.blocks.append(r)
 
     def activation_bytes(self):
         tot = 0
@@ -684,6 +726,13 @@ class ViTEngine:
     def block_forward(self, l, x_in, x_out, a, training):
         cfg = self.cfg
         rate, key = self._keys(training)
+        if self.c_blocks:
+            r = self.blocks[l]
+            r.key_attn, r.key_proj, r.key_mlp = key(rng.site_attn(l)), key(rng.site_proj(l)), key(rng.site_mlp(l))
+            if not self.training:
+                r.x_in, r.x_out = x_in.data_ptr(), x_out.data_ptr()
+            _lib.call("chb_vit_block_fwd", ctypes.byref(r), 1 if (training and rate) else 0, K._s())
+            return
         d, M, Mg = cfg.patch_dim, self.M, self.Mg
         pre = "encoder/layer_%d/" % l
         K.layernorm_fwd(x_in, d, self.p(pre + "norm1/gamma"), self.p(pre + "norm1/beta"), a["h1"], a["mean1"], a["rstd1"], M, d,
@@ -824,7 +873,7 @@ class ViTEngine:
         side = self.side if self.overlap_wgrad else None
 
         def nxt(name):          # next buffer of an operand the side stream reads (a ring slot, or the one buffer)
-            if side is None:
+            if side is None or self.c_blocks:       # the C block entries order re-use of the one buffer by events of their own
                 return getattr(self, name)
             buf = getattr(self, name + "_ring").acquire()
             setattr(self, name, buf)      # the attribute always names the latest version (tests and tools read it after backward)
@@ -870,7 +919,7 @@ class ViTEngine:
         if not fuse_tail:     # distilled variant: two LayerNorm launches write dx (class rows, distillation rows); dz follows them
             K.dropout_bwd(self.dx, nxt("dz"), M, d, rate, key(rng.site_mlp(L - 1)))
             K.colsum(self.dz, self.g(last), m=M)
-        for l in reversed(range(L)):
+        for l in reversed(range(L) if not self.c_blocks else ()):
             a = self.acts[l]
             pre = "encoder/layer_%d/" % l
             # MLP branch (self.dz = dropout-backward of dx at site_mlp(l))
@@ -908,6 +957,30 @@ class ViTEngine:
                 K.layernorm_bwd(self.dh, self.xs[l], d, a["mean1"], a["rstd1"], self.p(pre + "norm1/gamma"), self.dx, d, True,
                                 self.g(pre + "norm1/gamma"), self.g(pre + "norm1/beta"), M, d)
             self.reducer.bucket_ready(2 * (L - l))
+        if self.c_blocks:
+            main_s = K._s()
+            side_p = ctypes.c_void_p(side.cuda_stream) if side is not None else None
+
+            def cjoin():
+                if side is not None:
+                    _lib.call("chb_side_stream_join", main_s, side_p)
+
+            for l in reversed(range(L)):
+                r = self.blocks[l]
+                r.key_attn, r.key_proj, r.key_mlp = key(rng.site_attn(l)), key(rng.site_proj(l)), key(rng.site_mlp(l))
+                r.key_prev_mlp = key(rng.site_mlp(l - 1)) if l > 0 else 0
+                if self.reducer.active:
+                    # this block's MLP / projection gradients and the previous block's QKV gradients are final after phase 1 and
+                    # adjacent in the flat buffer: one all-reduce, started beside the attention backward
+                    _lib.call("chb_vit_block_bwd", ctypes.byref(r), 1, main_s, side_p)
+                    self.reducer.bucket_ready(2 * (L - l) - 1)
+                    cjoin()           # the collective reads gradients the side stream wrote
+                    self.reducer.flush()
+                    _lib.call("chb_vit_block_bwd", ctypes.byref(r), 2, main_s, side_p)
+                else:
+                    _lib.call("chb_vit_block_bwd", ctypes.byref(r), 3, main_s, side_p)
+                self.reducer.bucket_ready(2 * (L - l))
+            cjoin()
         join()                    # AdamW (and the last collective) read every gradient
         # embedding stage
         K.embed_bwd(self.dx, self.dpatch, self.g("pos_embedding/embeddings"), self.g("add_cls_token/embeddings"), self.B, n, d, rate,

@@ -67,7 +67,7 @@ extern "C" {
 #define CHB_OUT_F32 1
 
 /* ---------------------------------------------------------------- library info */
-int chb_version(void);            /* ABI version, currently 3 (round 3) */
+int chb_version(void);            /* ABI version, currently 4 (round 4: block-level entries, launch profiler) */
 const char* chb_build_arch(void); /* "gfx950" */
 
 /* ---------------------------------------------------------------- augmentation (uint8 NHWC) */
@@ -406,6 +406,72 @@ int chb_scale_by_bf16(const void* dy, int dy_dtype, const void* aux_bf16, void* 
 int chb_dropout_f32(const float* x, float* out, int64_t n, float rate, uint32_t key, void* stream);
 int chb_add_rows_f32(const float* x, const float* table, float* out, int64_t n, int64_t period, void* stream);
 int chb_sum_rows_f32(const float* x, int64_t row_stride, int64_t rows, int64_t cols, float* out, void* stream);
+
+/* ---- one encoder block per call -------------------------------------------------------------------------------------------------
+ * EncoderLayer.call, pre-norm branch (layers/transformer.py:53-77; the block sequence of models/backbones/vision_transformer.py:
+ * 262-271) and its gradient as ONE host call each: chb_vit_block_fwd / _bwd issue, on `stream`, exactly the chb_layernorm_* /
+ * chb_gemm_* / chb_attention_* launches listed above with the arguments this record implies (same kernels, same order: results are
+ * bit-identical to driving those entries one by one); the caller fills the record once per block (all buffers are the caller's and
+ * static) and only updates the dropout site keys per step.  Nothing is allocated; no state is kept between calls except the events
+ * of the optional side stream.
+ *   token matrices have Mp rows (multiple of 256, >= M = B*N); GEMMs are launched over Mg rows (M, or Mp: pad rows hold finite junk
+ *   in the forward and exact zeros in the backward), reductions over tokens run over M.
+ *   bf16 matrices: *_wt = [out][in] images (forward B operands), *_w = [in][out] images (dgrad B operands), both refreshed by
+ *   chb_cast_transpose after every optimizer step; g_*_w fp32 [in][out] gradient accumulators (+=).
+ *   backward contract: on entry dx (fp32 [Mp,D]) holds d(loss)/d(x_out) and dz (bf16 [Mp,D]) its dropout-backward at this block's MLP
+ *   site (key_mlp) - written by the block above or by the final LayerNorm's fused tail; on exit dx holds d(loss)/d(x_in) and, with
+ *   emit_dz != 0, dz its dropout-backward at the MLP site of the block BELOW (key_prev_mlp) with the column sums added to
+ *   g_prev_fc2_bias (that block's dense2 bias gradient).
+ *   phases (backward): bit 0 = MLP branch + output projection, bit 1 = attention core + QKV projection + LayerNorm 1.  A data-parallel
+ *   caller runs phase 1, starts the all-reduce of the gradients that are now final, then phase 2 (engine.py GradBucketReducer);
+ *   phases = 3 runs the whole block.
+ *   side_stream (backward, optional): the four weight-gradient GEMMs go to this second stream (fork / join by events inside the
+ *   call; they depend only on saved activations and on dz / da1 / dqkv, and only the optimizer reads their output), using tn_ws_side
+ *   as their split-K scratch; chb_side_stream_join makes `stream` wait for everything issued there (call it before the optimizer or
+ *   a collective reads the weight gradients).  NULL: everything on `stream`. */
+typedef struct chb_vit_block {
+    int32_t B, N, H, hd, D, FF;             /* images, tokens per image, heads, head dim (64), model width, MLP width */
+    int32_t M, Mg, Mp;                      /* B*N token rows; rows the GEMMs are launched over; allocated rows */
+    float eps, drop_rate;                   /* LayerNorm epsilon (1e-6, layers/transformer.py:20); dropout rate of the three sites */
+    uint32_t key_attn, key_proj, key_mlp;   /* dropout site keys of this block for this step */
+    uint32_t key_prev_mlp;                  /* backward: MLP site key of the block below */
+    int32_t emit_dz;                        /* backward: 0 for the lowest block (the embedding stage takes dx) */
+    int32_t reserved;
+    const float *ln1_gamma, *ln1_beta, *ln2_gamma, *ln2_beta, *qkv_bias, *proj_bias, *fc1_bias, *fc2_bias;
+    const void *qkv_wt, *proj_wt, *fc1_wt, *fc2_wt;
+    const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    const float* x_in;                      /* fp32 [Mp,D] block input (saved: LayerNorm 1 backward reads it) */
+    float* x_out;                           /* fp32 [Mp,D] */
+    void *h1, *qkv, *o, *h2, *a1, *u;       /* bf16 [Mp,D], [Mp,3D], [Mp,D], [Mp,D], [Mp,FF] (gelu'), [Mp,FF] (gelu) */
+    float *mean1, *rstd1, *lse, *xmid, *mean2, *rstd2;   /* fp32 [Mp], [Mp], [B*H*N], [Mp,D], [Mp], [Mp] */
+    uint32_t* drop_bits;                    /* keep bits of the attention dropout (chb_attention_fwd), or NULL */
+    float *g_ln1_gamma, *g_ln1_beta, *g_ln2_gamma, *g_ln2_beta, *g_qkv_bias, *g_proj_bias, *g_fc1_bias, *g_prev_fc2_bias;
+    float *g_qkv_w, *g_proj_w, *g_fc1_w, *g_fc2_w;
+    float* dx;                              /* fp32 [Mp,D] residual-stream gradient, in / out */
+    void *dz, *da1, *dh, *d_o, *dqkv;       /* bf16 scratch [Mp,D], [Mp,FF], [Mp,D], [Mp,D], [Mp,3D]; dz in / out */
+    float *tn_ws, *tn_ws_side;              /* split-K scratch of the weight-gradient GEMMs (chb_gemm_tn_ws), tn_ws_bytes each */
+    int64_t tn_ws_bytes;
+} chb_vit_block;
+int chb_vit_block_fwd(const chb_vit_block* block_host, int training, void* stream);
+int chb_vit_block_bwd(const chb_vit_block* block_host, int phases, void* stream, void* side_stream);
+int chb_side_stream_join(void* stream, void* side_stream);
+
+/* ---- launch profiler -----------------------------------------------------------------------------------------------------------
+ * chb_profile_enable(1) starts a period (dropping earlier records): from then on chb_gemm_nt and chb_gemm_tn / chb_gemm_tn_ws -
+ * called directly or from chb_vit_block_* - record a HIP event on their launch stream right before and right after the GEMM launch
+ * (for the weight gradients: the GEMM alone, not the fold of its split-K planes).  chb_profile_enable(0) stops recording.
+ * chb_profile_collect waits for the recorded events and copies up to max_records records to HOST memory; *n_records_host = how many
+ * exist.  kind 0 = chb_gemm_nt (family 1: 128x128 tiles, 2 / 4 / 5: the persistent 256x256 kernels - lockstep, ping-pong, pipelined),
+ * kind 1 = weight gradient (family 0: small, 1: persistent 256x256); m, n, k as passed (k = reduction length);
+ * ms = launch duration, start_ms = its start relative to the period's first record (launches of two streams may overlap).
+ * Recording is skipped while a stream is being captured into a graph.  Host-side bookkeeping only: no device state. */
+typedef struct chb_profile_record {
+    int32_t kind, family, epilogue, out_dtype;
+    int64_t m, n, k;
+    float ms, start_ms;
+} chb_profile_record;
+int chb_profile_enable(int on);
+int chb_profile_collect(chb_profile_record* out_host, int max_records, int* n_records_host);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), "libchambers_hip.so lacks %s" % name
     typed = _lib.load()
-    assert typed.chb_version() == 3 and typed.chb_build_arch() == b"gfx950"
+    assert typed.chb_version() == 4 and typed.chb_build_arch() == b"gfx950"
     # every declared entry has a ctypes prototype (and vice versa)
     assert set(_declared()) == set(_lib.PROTOTYPES) | set(_lib.INFO_SYMBOLS)
 

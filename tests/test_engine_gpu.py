@@ -365,6 +365,66 @@ def test_full_size_gemm_linearity_and_wgrad_identity():
     assert abs(lhs - rhs) <= 1e-6 * float((x.double().abs().sum(1) * dy.double().abs().sum(1)).sum())
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_block_level_c_entries_are_bit_identical_to_the_launch_by_launch_path(overlap):
+    """chb_vit_block_fwd / chb_vit_block_bwd (one C-ABI call per encoder block and direction) issue the same launches
+    in the same order as the Python engine did one ctypes call at a time: logits, the loss, the residual-stream gradient and the
+    operands of the last block's GEMMs agree BIT FOR BIT; the flat gradient agrees to the order of the fp32 atomics of the small
+    split-K reductions (the only run-to-run freedom of a backward pass).  With overlap: the C path's side stream (events inside the
+    call, single operand buffers) against the Python path's rings."""
+    from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
+    cfg = ViTConfig(patch_size=16, patch_dim=256, n_encoder_layers=4, n_heads=4, ff_dim=1024, image_size=(96, 96), classes=16, dropout_rate=0.1)
+    kw = init_keras_weights(cfg, seed=5)
+    g = np.random.Generator(np.random.PCG64(11))
+    labels = torch.as_tensor(g.integers(0, 16, size=(48,)).astype(np.int32), device="cuda")
+    batches = [torch.as_tensor(g.integers(0, 256, size=(48, 96, 96, 3), dtype=np.uint8), device="cuda") for _ in range(3)]
+    runs = []
+    for c_blocks in (False, True):
+        eng = ViTEngine(cfg, 48, training=True, seed=3, overlap_wgrad=overlap)
+        eng.c_blocks = c_blocks
+        eng.load_keras_weights(kw)
+        out = []
+        for images in batches:
+            logits = eng.forward(images, training=True).clone()
+            loss = eng.loss(labels).clone()
+            eng.backward()
+            torch.cuda.synchronize()
+            out.append((logits, loss, eng.dx.clone(), eng.dqkv.clone(), eng.da1.clone(), eng.dpatch.clone(), eng.G.clone()))
+        runs.append(out)
+    for a, b in zip(*runs):
+        for k in range(6):
+            assert torch.equal(a[k].view(torch.int32) if a[k].dtype == torch.float32 else a[k].view(torch.int16),
+                               b[k].view(torch.int32) if b[k].dtype == torch.float32 else b[k].view(torch.int16)), k
+        assert float(a[6].abs().max()) > 0 and rel_l2(b[6].cpu(), a[6].cpu()) < 1e-6
+
+
+def test_launch_profiler_records_every_gemm_of_a_step():
+    """chb_profile_enable / chb_profile_collect (include/chambers_hip.h): HIP events recorded inside chb_gemm_nt / chb_gemm_tn_ws on
+    their launch stream - bench.py's live roofline - see the GEMMs issued from inside the block-level calls: 8 NT + 4 weight-gradient
+    GEMMs per block, the patch embedding and the two head GEMMs + their weight gradients."""
+    from chambers_amd import _lib
+    cfg = _cfg()
+    eng, kw, images, labels = _setup(cfg, 6, training=True)
+    x = torch.as_tensor(images, device="cuda")
+    y = torch.as_tensor(labels.astype(np.int32), device="cuda")
+    eng.train_step(x, y)
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    eng.train_step(x, y)
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    recs = _lib.profile_collect()
+    L = cfg.n_encoder_layers
+    nt = [r for r in recs if r["kind"] == 0]
+    tn = [r for r in recs if r["kind"] == 1]
+    assert len(nt) == 8 * L + 1 + 2 and len(tn) == 4 * L + 1 + 1, (len(nt), len(tn))
+    assert all(r["ms"] > 0 and r["m"] > 0 and r["n"] > 0 and r["k"] > 0 for r in recs)
+    assert recs[0]["start_ms"] == 0 and all(b["start_ms"] >= a["start_ms"] for a, b in zip(recs, recs[1:]))
+    eng.train_step(x, y)                      # recording is off again: nothing is added
+    torch.cuda.synchronize()
+    assert len(_lib.profile_collect()) == len(recs)
+
+
 def test_side_stream_weight_gradients_change_nothing():
     """overlap_wgrad=True runs a block's four weight-gradient GEMMs on a second stream (operand rings, events both ways): same
     kernels, same operands per gradient - the flat gradient agrees to the order of the fp32 atomics that fold bias-gradient column
