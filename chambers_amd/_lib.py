@@ -92,6 +92,8 @@ PROTOTYPES = {
     "chb_dropout_f32": [P, P, c_int64, c_float, ctypes.c_uint32, P],
     "chb_add_rows_f32": [P, P, P, c_int64, c_int64, P],
     "chb_sum_rows_f32": [P, c_int64, c_int64, c_int64, P, P],
+    "chb_axpby_f32": [P, c_float, P, c_float, P, c_int64, P],
+    "chb_add_rows_bf16": [P, c_int64, P, c_int64, c_int64, c_int, P],
     "chb_vit_block_fwd": [P, c_int, P],
     "chb_vit_block_bwd": [P, c_int, P, P],
     "chb_side_stream_join": [P, P],

@@ -379,6 +379,24 @@ __global__ void __launch_bounds__(256) add_f32_kernel(const float* __restrict__ 
         for (int64_t i = n4 * 4; i < n; ++i) out[i] = a[i] + b[i];
 }
 
+// out = alpha * a (+ beta * b): the average of the two heads of the distilled variant and its backward (vision_transformer.py:373-397)
+__global__ void __launch_bounds__(256) axpby_f32_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b, float beta,
+                                                        float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = b ? alpha * a[i] + beta * b[i] : alpha * a[i];
+}
+
+// x[r][c] = bf16(x[r][c] + y[r][c]) over strided bf16 rows (fp32 sum, one rounding)
+__global__ void __launch_bounds__(256) add_rows_bf16_kernel(bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ y, int64_t ldy, int64_t rows,
+                                                            int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        x[r * ldx + c] = f32_to_bf16(bf16_to_f32(x[r * ldx + c]) + bf16_to_f32(y[r * ldy + c]));
+    }
+}
+
 __global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f32_to_bf16(src[i]);
 }
@@ -584,6 +602,23 @@ int chb_add_f32(const float* a, const float* b, float* out, int64_t n, void* str
     if (!a || !b || !out || n < 0) return CHB_EINVAL;
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return CHB_EINVAL;
     hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, n);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, int64_t n, void* stream) {
+    if (n == 0) return CHB_OK;
+    if (!a || !out || n < 0) return CHB_EINVAL;
+    hipLaunchKernelGGL(axpby_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, alpha, b, beta, out, n);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_add_rows_bf16(void* x_bf16, int64_t ldx, const void* y_bf16, int64_t ldy, int64_t rows, int cols, void* stream) {
+    if (rows == 0 || cols == 0) return CHB_OK;
+    if (!x_bf16 || !y_bf16 || rows < 0 || cols < 0 || ldx < cols || ldy < cols) return CHB_EINVAL;
+    hipLaunchKernelGGL(add_rows_bf16_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x_bf16, ldx, (const bf16_t*)y_bf16, ldy,
+                       rows, cols);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

@@ -796,14 +796,15 @@ class ViTEngine:
             K.layernorm_fwd(x.view(-1)[d:], n * d, self.p("encoder/norm/gamma"), self.p("encoder/norm/beta"), self.hfd, self.meand, self.rstdd,
                             self.B, d, cfg.norm_epsilon)
         else:
-            self.hfd[:self.B].copy_(self.hn[:self.M].view(self.B, n, d)[:, 1, :])
+            K.store_rows(self.hfd[:self.B], self.hn[:self.M].view(self.B, n * d)[:, d:2 * d])      # sequence row 1 of every image
         if cfg.include_top:
             K.gemm_nt(head_in, self.wbt("predictions/kernel"), self.logits, m=self.B, bias=self.p("predictions/bias"))
             K.gemm_nt(self.hfd, self.wbt("predictions_dist/kernel"), self.logits_dist, m=self.B, bias=self.p("predictions_dist/bias"))
-            a, b = self.logits[:self.B, :cfg.classes], self.logits_dist[:self.B, :cfg.classes]
-        else:
-            a, b = self.hf[:self.B].float(), self.hfd[:self.B].float()
-        return (a, b) if cfg.return_dist_token else (a + b) * 0.5
+            if not cfg.return_dist_token:       # the average of the two heads, formed on the padded buffers
+                return K.axpby_f32(self.logits, 0.5, self.logits_dist, 0.5)[:self.B, :cfg.classes]
+            return self.logits[:self.B, :cfg.classes], self.logits_dist[:self.B, :cfg.classes]
+        a, b = K.cast_f32(self.hf[:self.B]), K.cast_f32(self.hfd[:self.B])
+        return (a, b) if cfg.return_dist_token else K.axpby_f32(a, 0.5, b, 0.5)
 
     def capture_inference(self):
         """Capture the inference forward (normalise + patchify -> logits, ~100 launches for ViT-B/16) into a HIP graph over the
@@ -860,11 +861,11 @@ class ViTEngine:
         elif cfg.pooling == "none":
             if doutput is None or tuple(doutput.shape) != (self.B, n, d):
                 raise ValueError("pooling=None: pass doutput of shape %s" % ((self.B, n, d),))
-            self.dh[:M].copy_(doutput.reshape(M, d))
+            K.store_rows(self.dh[:M], doutput.reshape(M, d))
         else:
             if doutput is None or tuple(doutput.shape) != (self.B, F or d):
                 raise ValueError("include_top=False: pass doutput of shape %s" % ((self.B, F or d),))
-            (self.dfeat[:self.B, :F] if F else self.dhf[:self.B]).copy_(doutput)
+            K.store_rows(self.dfeat[:self.B, :F] if F else self.dhf[:self.B], doutput)
         if F:
             K.tanh_bwd(self.dfeat, self.feat, self.dfz)
             K.gemm_tn(self.hf, self.dfz, self.g("feature/kernel"), m=self.Bp, ws=self.tn_ws)
@@ -911,8 +912,7 @@ class ViTEngine:
             if cfg.pooling != "none":
                 K.pool_tokens_bwd(self.dhf, self.pool_arg, self.dh, self.B, n, d, cfg.pooling)
             if cfg.distilled:   # add the distillation head's gradient to row 1 of the normalised sequence
-                dhv = self.dh[:M].view(self.B, n, d)
-                dhv[:, 1, :] += self.dhfd[:self.B]
+                K.add_rows_bf16(self.dh[:M].view(self.B, n * d)[:, d:2 * d], self.dhfd[:self.B])
             K.layernorm_bwd(self.dh, self.x_final, d, self.meanf, self.rstdf, self.p("encoder/norm/gamma"), self.dx, d, False,
                             self.g("encoder/norm/gamma"), self.g("encoder/norm/beta"), M, d, **tail)
         self.reducer.bucket_ready(0)
@@ -1000,13 +1000,13 @@ class ViTEngine:
         if cfg.return_dist_token:
             da, db = doutput
         else:
-            da = db = doutput * 0.5
+            da = db = K.axpby_f32(doutput.to(torch.float32) if doutput.dtype != torch.float32 else doutput, 0.5)
         width = cfg.classes if cfg.include_top else d
         if tuple(da.shape) != (self.B, width) or tuple(db.shape) != (self.B, width):
             raise ValueError("doutput tensors must have shape %s" % ((self.B, width),))
         if cfg.include_top:
-            self.dlogits[:self.B, :cfg.classes].copy_(da)
-            self.dlogits_dist[:self.B, :cfg.classes].copy_(db)
+            K.store_rows(self.dlogits[:self.B, :cfg.classes], da)
+            K.store_rows(self.dlogits_dist[:self.B, :cfg.classes], db)
             K.gemm_tn(self.hf, self.dlogits, self.g("predictions/kernel"), m=self.Bp, ws=self.tn_ws)
             K.colsum(self.dlogits, self.g("predictions/bias"), m=self.B)
             K.gemm_nt(self.dlogits, self.wb("predictions/kernel"), self.dhf, m=self.B)
@@ -1014,8 +1014,8 @@ class ViTEngine:
             K.colsum(self.dlogits_dist, self.g("predictions_dist/bias"), m=self.B)
             K.gemm_nt(self.dlogits_dist, self.wb("predictions_dist/kernel"), self.dhfd, m=self.B)
         else:
-            self.dhf[:self.B].copy_(da)
-            self.dhfd[:self.B].copy_(db)
+            K.store_rows(self.dhf[:self.B], da)
+            K.store_rows(self.dhfd[:self.B], db)
 
     # ---- optimizer ------------------------------------------------------------------------
     def adamw_step(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, weight_decay=0.0, zero_grad=True):

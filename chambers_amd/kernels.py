@@ -641,6 +641,44 @@ def add_f32(a, b, out=None):
     return out
 
 
+def axpby_f32(a, alpha, b=None, beta=0.0):
+    """alpha * a (+ beta * b), fp32, contiguous tensors of one shape."""
+    _lib.require_gpu(a, b)
+    if a.dtype != torch.float32 or (b is not None and (b.dtype != torch.float32 or b.shape != a.shape)):
+        raise ValueError("axpby_f32 takes fp32 tensors of one shape")
+    a = a.contiguous()
+    b = b.contiguous() if b is not None else None
+    out = torch.empty_like(a)
+    _lib.call("chb_axpby_f32", _lib.ptr(a), float(alpha), _lib.ptr(b), float(beta), _lib.ptr(out), a.numel(), _s())
+    return out
+
+
+def add_rows_bf16(x, y):
+    """x += y for 2-D bf16 views whose rows are contiguous (any row stride): fp32 sum, one rounding."""
+    _lib.require_gpu(x, y)
+    if x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or x.dim() != 2 or x.shape != y.shape or x.stride(1) != 1 or y.stride(1) != 1:
+        raise ValueError("add_rows_bf16 takes two 2-D bf16 views of one shape with contiguous rows")
+    _lib.call("chb_add_rows_bf16", _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), x.shape[0], x.shape[1], _s())
+    return x
+
+
+def store_rows(dst, src):
+    """dst[...] = src for a 2-D destination view with contiguous rows (any row stride): a cast kernel when the dtypes differ
+    (fp32 -> bf16, round to nearest even; bf16 -> fp32), then a strided row copy - no torch arithmetic."""
+    _lib.require_gpu(dst, src)
+    if dst.dim() != 2 or dst.stride(1) != 1 or tuple(src.shape) != tuple(dst.shape):
+        raise ValueError("store_rows: dst must be a 2-D view with contiguous rows and src must have its shape; got %s <- %s" % (tuple(dst.shape), tuple(src.shape)))
+    if src.dtype != dst.dtype:
+        src = cast_bf16(src) if dst.dtype == torch.bfloat16 else cast_f32(src)
+    if src.stride(1) != 1:
+        src = src.contiguous()
+    es = dst.element_size()
+    if (dst.shape[1] * es) % 4 or (dst.stride(0) * es) % 4 or (src.stride(0) * es) % 4:
+        raise ValueError("store_rows: row bytes and strides must be multiples of 4")
+    _lib.call("chb_copy_rows", _lib.ptr(src), src.stride(0) * es, _lib.ptr(dst), dst.stride(0) * es, dst.shape[0], dst.shape[1] * es, _s())
+    return dst
+
+
 def cast_bf16(x, out=None):
     """fp32 -> bf16 (round to nearest even), a bf16 tensor is returned as it is.  out: a contiguous bf16 buffer with at least
     x.numel() elements whose head receives the result (rows of a zero-padded operand); a bf16 x is copied there."""

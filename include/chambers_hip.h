@@ -388,6 +388,12 @@ int chb_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int chb_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 int chb_copy_rows(const void* src, int64_t src_stride_bytes, void* dst, int64_t dst_stride_bytes, int64_t rows, int64_t row_bytes, void* stream);
 int chb_softmax_f32(const float* x, int64_t ld, float* out, int64_t ld_out, int rows, int cols, void* stream);
+/* The two outputs of DistilledVisionTransformer (vision_transformer.py:373-397: class-token head and distillation-token head, a pair or
+ * their average): out = alpha * a + beta * b (fp32; b may be NULL: out = alpha * a) - the average and its backward;
+ * x[r][c] = bf16(x[r][c] + y[r][c]) over strided bf16 rows (ld in elements) - the distillation head's gradient joining row 1 of the
+ * normalised sequence. */
+int chb_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, int64_t n, void* stream);
+int chb_add_rows_bf16(void* x_bf16, int64_t ldx, const void* y_bf16, int64_t ldy, int64_t rows, int cols, void* stream);
 
 /* Pieces of the TRAINABLE stand-alone layers (chambers_amd/layers: torch.autograd.Function wrappers over this ABI; the whole-model
  * engine has these fused into its GEMM / LayerNorm epilogues):
