@@ -83,9 +83,10 @@ PROTOTYPES = {
     "chb_softmax_f32": [P, c_int64, P, c_int64, c_int, c_int, P],
     "chb_set_option": [ctypes.c_char_p, c_int],
     "chb_gemm_tile_queue_reset": [P],
-    "chb_attention_general_fwd": [P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_float, c_uint32, P],
+    "chb_attention_general_fwd": [P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_float, c_uint32,
+                                  c_float, P],
     "chb_attention_general_bwd": [P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P,
-                                  c_int, c_float, c_uint32, P],
+                                  c_int, c_float, c_uint32, c_float, P],
     "chb_gelu_f32": [P, P, P, c_int64, c_int, P],
     "chb_mul_f32": [P, P, P, c_int64, P],
     "chb_scale_by_bf16": [P, c_int, P, P, c_int64, P],

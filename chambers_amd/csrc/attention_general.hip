@@ -159,15 +159,18 @@ extern "C" {
 
 int chb_attention_general_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
                               float* lse, int B, int Tq, int Tk, int H, int hd, const uint8_t* value_mask, const uint8_t* query_mask,
-                              int causal, float drop_rate, uint32_t drop_key, void* stream) {
+                              int causal, float drop_rate, uint32_t drop_key, float scale, void* stream) {
     const int rc = ga_check(q, k, v, B, Tq, Tk, H, hd, drop_rate);
     if (rc != CHB_OK) return rc;
     if (!o || !lse || (ldq & 1) || (ldk & 1)) return CHB_EINVAL;
     if (B == 0) return CHB_OK;
     GaParams p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, B, Tq, Tk, H, hd, value_mask, query_mask, causal,
-               1.0f / sqrtf((float)hd), 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key};
+               scale > 0.f ? scale : 1.0f / sqrtf((float)hd), 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key};
     const size_t lds = (size_t)4 * (GA_MAX_HD + Tk) * sizeof(float);
-    static std::atomic<bool> attr{false};        // once per process: a driver call, not per launch
+    static std::atomic<bool> attr_fwd[64];       // once per DEVICE (the attribute is per device): a driver call, not per launch
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CHB_ELAUNCH;
+    std::atomic<bool>& attr = attr_fwd[dev];
     if (!attr.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)ga_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (GA_MAX_HD + GA_MAX_TK) * 4) != hipSuccess)
             return CHB_ELAUNCH;
@@ -181,15 +184,18 @@ int chb_attention_general_fwd(const void* q, int64_t ldq, const void* k, int64_t
 int chb_attention_general_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
                               const void* d_o, int64_t ldg, const float* lse, float* dq, float* dk, float* dv, int B, int Tq, int Tk, int H,
                               int hd, const uint8_t* value_mask, const uint8_t* query_mask, int causal, float drop_rate, uint32_t drop_key,
-                              void* stream) {
+                              float scale, void* stream) {
     const int rc = ga_check(q, k, v, B, Tq, Tk, H, hd, drop_rate);
     if (rc != CHB_OK) return rc;
     if (!o || !d_o || !lse || !dq || !dk || !dv || (ldq & 1) || (ldk & 1)) return CHB_EINVAL;
     if (B == 0) return CHB_OK;
     GaParams p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, B, Tq, Tk, H, hd, value_mask, query_mask, causal,
-               1.0f / sqrtf((float)hd), 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key};
+               scale > 0.f ? scale : 1.0f / sqrtf((float)hd), 1.0f / (1.0f - drop_rate), drop_rate > 0.f ? chb_drop_threshold(drop_rate) : 0u, drop_key};
     const size_t lds = (size_t)4 * (2 * GA_MAX_HD + 2 * Tk) * sizeof(float);
-    static std::atomic<bool> attr{false};
+    static std::atomic<bool> attr_bwd[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CHB_ELAUNCH;
+    std::atomic<bool>& attr = attr_bwd[dev];
     if (!attr.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)ga_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (2 * GA_MAX_HD + 2 * GA_MAX_TK) * 4) != hipSuccess)
             return CHB_ELAUNCH;

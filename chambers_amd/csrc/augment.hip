@@ -1312,7 +1312,9 @@ __device__ __forceinline__ bool affine_source(const FusedOp& o, int W, int H, in
 // (profiles/r03_augment_stage.txt note (h)); behind this opaque move the same build is bit-exact.  One v_mov per level.
 __device__ __forceinline__ uint32_t vgpr_byte(int v) {
     uint32_t r = (uint32_t)v & 0xffu;
+#ifndef CHB_NO_VGPR_BYTE          /* tools/check_byte_select_isa.py builds the unguarded variant to show what the guard removes */
     asm volatile("" : "+v"(r));
+#endif
     return r;
 }
 
@@ -2606,6 +2608,13 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
             if (hipEventRecord(gs->join[k], gs->side[k]) != hipSuccess || hipStreamWaitEvent(s0, gs->join[k], 0) != hipSuccess) return false;
         return true;
     };
+    // once side streams have been forked, EVERY exit joins them again (best effort on an error path): an unjoined branch invalidates a
+    // stream capture, and outside one the caller may free the workspace while a side-stream kernel still uses it
+    bool forked = false;
+    auto fail = [&]() -> int {
+        if (forked) (void)join(0, 2);
+        return CHB_ELAUNCH;
+    };
     const FusedOp* items = (const FusedOp*)items_dev;
     FusedParams P;
     memset(&P, 0, sizeof(P));
@@ -2658,7 +2667,8 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
         s = s0;
     };
     if (order_dev) {            // the chains without a table op have nothing to wait for: beside the table levels, the long pole alone
-        if (!fork(0, 2)) return CHB_ELAUNCH;
+        forked = true;          // a partial fork may already have made a side stream wait
+        if (!fork(0, 2)) return fail();
         final_group(2, gs->side[0]);
         final_group(0, gs->side[1]);
         final_group(1, gs->side[1]);
@@ -2695,7 +2705,7 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
         FusedParams Q = P;
         Q.order = order_dev + (int64_t)(l + 1) * B;
         const bool spread = (cn[0] != 0) + (cn[1] != 0) + (cn[2] != 0) > 1;
-        if (spread && !fork(2, 2)) return CHB_ELAUNCH;
+        if (spread && !fork(2, 2)) return fail();
         for (int g = 0; g < 3; ++g) {
             if (cn[g]) {
                 const dim3 grid(sl, cn[g]);
@@ -2707,7 +2717,7 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
             Q.n0 += cn[g];
         }
         s = s0;
-        if (spread && !join(2, 2)) return CHB_ELAUNCH;
+        if (spread && !join(2, 2)) return fail();
         hipLaunchKernelGGL(fused_lut_kernel, dim3(tot * 3), dim3(256), 0, s, t, part, sl, 0, items + (int64_t)l * B, Q.order);
 #undef CHB_ITEMS_HIST_L
 #undef CHB_ITEMS_HIST
@@ -2717,11 +2727,11 @@ static int fused_items_run(const uint8_t* in, void* out, int B, int H, int W, in
         const dim3 grid((hh + 15) / 16, B);
         CHB_ITEMS_FINAL_N(CHB_ITEMS_FINAL, FUSED_ITEMS, grid);
     } else {                    // the chains with tables behind the table launches
-        if ((counts[3] || counts[4]) && !fork(2, 2)) return CHB_ELAUNCH;
+        if ((counts[3] || counts[4]) && !fork(2, 2)) return fail();
         final_group(5, s0);
         final_group(3, gs->side[2]);
         final_group(4, gs->side[2]);
-        if (!join(0, 2)) return CHB_ELAUNCH;
+        if (!join(0, 2)) return fail();
     }
 #undef CHB_ITEMS_LOCAL
 #undef CHB_ITEMS_FINAL

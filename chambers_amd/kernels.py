@@ -825,18 +825,18 @@ def _mask_u8(m, b, t, device):
     return (m != 0).to(torch.uint8).contiguous()
 
 
-def attention_general_fwd(q, k, v, b, tq, tk, h, hd, value_mask=None, query_mask=None, causal=False, drop_rate=0.0, drop_key=0):
+def attention_general_fwd(q, k, v, b, tq, tk, h, hd, value_mask=None, query_mask=None, causal=False, drop_rate=0.0, drop_key=0, scale=0.0):
     """q [B*Tq, H*hd], k / v [B*Tk, H*hd] bf16 -> (o bf16 [B*Tq, H*hd], lse fp32 [B*H*Tq]); masks uint8 [B, T] or None."""
     _lib.require_gpu(q, k, v, value_mask, query_mask)
     o = torch.empty((b * tq, h * hd), dtype=torch.bfloat16, device=q.device)
     lse = torch.empty(b * h * tq, dtype=torch.float32, device=q.device)
     _lib.call("chb_attention_general_fwd", _lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0), _lib.ptr(o), o.stride(0),
               _lib.ptr(lse), int(b), int(tq), int(tk), int(h), int(hd), _lib.ptr(value_mask), _lib.ptr(query_mask), int(bool(causal)),
-              float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+              float(drop_rate), ctypes.c_uint32(int(drop_key)), float(scale), _s())
     return o, lse
 
 
-def attention_general_bwd(q, k, v, o, d_o, lse, b, tq, tk, h, hd, value_mask=None, query_mask=None, causal=False, drop_rate=0.0, drop_key=0):
+def attention_general_bwd(q, k, v, o, d_o, lse, b, tq, tk, h, hd, value_mask=None, query_mask=None, causal=False, drop_rate=0.0, drop_key=0, scale=0.0):
     """-> (dq fp32 [B*Tq, H*hd], dk, dv fp32 [B*Tk, H*hd])."""
     _lib.require_gpu(q, k, v, o, d_o, lse, value_mask, query_mask)
     dq = torch.empty((b * tq, h * hd), dtype=torch.float32, device=q.device)
@@ -844,5 +844,5 @@ def attention_general_bwd(q, k, v, o, d_o, lse, b, tq, tk, h, hd, value_mask=Non
     dv = torch.zeros((b * tk, h * hd), dtype=torch.float32, device=q.device)
     _lib.call("chb_attention_general_bwd", _lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0), _lib.ptr(o), o.stride(0),
               _lib.ptr(d_o), d_o.stride(0), _lib.ptr(lse), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), int(b), int(tq), int(tk), int(h), int(hd),
-              _lib.ptr(value_mask), _lib.ptr(query_mask), int(bool(causal)), float(drop_rate), ctypes.c_uint32(int(drop_key)), _s())
+              _lib.ptr(value_mask), _lib.ptr(query_mask), int(bool(causal)), float(drop_rate), ctypes.c_uint32(int(drop_key)), float(scale), _s())
     return dq, dk, dv

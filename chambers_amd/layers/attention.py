@@ -43,17 +43,19 @@ class ScaledAttention(Layer):
         k = inputs[2] if len(inputs) > 2 else v
         b, h, t, hd = q.shape
         tk = k.shape[2]
-        if self.key_dim is not None and int(self.key_dim) != int(hd):
-            raise ValueError("key_dim %r does not match the head dimension %d of the inputs" % (self.key_dim, hd))
+        # scores / sqrt(key_dim) whenever a key_dim was given, whatever the width of the tensors (:13-22); the fused kernel has
+        # 1 / sqrt(64) built in, so another scale takes the general kernel
+        other_scale = self.key_dim is not None and int(self.key_dim) != int(hd)
         d = h * hd
         rate = self.dropout if training else 0.0
         dkey = (_next_key(self._site) if key is None else key) if rate else 0
         qmask, vmask = _split_mask(mask, b, t, tk, q.device)
-        general = qmask is not None or vmask is not None or self.causal or k.shape != q.shape or v.shape != q.shape or hd != 64
+        general = qmask is not None or vmask is not None or self.causal or k.shape != q.shape or v.shape != q.shape or hd != 64 or other_scale
         if general:
             # masks / causal / cross-attention / other head widths: keras Attention's full semantics through the general kernel
             flat = lambda x: x.permute(0, 2, 1, 3).reshape(x.shape[0] * x.shape[2], d)     # noqa: E731
-            o = AG.AttentionGeneralFn.apply(flat(q), flat(k), flat(v), b, t, tk, h, hd, vmask, qmask, self.causal, rate, dkey)
+            o = AG.AttentionGeneralFn.apply(flat(q), flat(k), flat(v), b, t, tk, h, hd, vmask, qmask, self.causal, rate, dkey,
+                                            1.0 / self._scale if other_scale else 0.0)
             return o.reshape(b, t, h, hd).permute(0, 2, 1, 3)
         # pack [q | k | v] as the fused kernel wants them: [B*T, 3*H*hd] (pure data movement: permute + concatenate; autograd routes
         # the packed gradient back through the same views)

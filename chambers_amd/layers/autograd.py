@@ -11,6 +11,7 @@ outputs, gelu(a) and gelu'(a), bf16 dY operands in backward.  No Function falls 
 Layer variables are leaf tensors with requires_grad (chambers_amd/_keras_like.Variable); after `loss.backward()` the gradients
 are in `variable.value.grad`, and `chambers_amd.optimizers.AdamW.apply_gradients` consumes them."""
 import ctypes
+import weakref
 
 import torch
 
@@ -22,25 +23,54 @@ def _pad64(n):
     return (int(n) + 63) // 64 * 64
 
 
-def _bf16_rows(x2d):
+def _bf16_rows(x2d, pad=True):
     """bf16 copy of a [M, K] matrix in a buffer of ceil(M / 64) * 64 rows whose tail rows are zero: the weight-gradient GEMM reduces
-    over whole 64-row steps, and zero rows add nothing.  Returns (buffer, view of the first M rows)."""
+    over whole 64-row steps, and zero rows add nothing.  Returns (buffer, view of the first M rows).  pad=False (nothing will be
+    differentiated): no zero fill, no tail rows."""
     m, k = x2d.shape
+    if not pad:
+        buf = K.cast_bf16(x2d.contiguous())
+        buf = buf.clone() if buf.data_ptr() == x2d.data_ptr() else buf       # never hand the caller's own storage on as "the copy"
+        return buf, buf
     buf = torch.zeros((_pad64(m), k), dtype=torch.bfloat16, device=x2d.device)
     K.cast_bf16(x2d, out=buf)
     return buf, buf[:m]
+
+
+# bf16 operand images of a layer's fp32 kernel, kept while the kernel has not changed: repeated calls of a stand-alone layer
+# (inference, or several forwards per optimizer step) re-use them instead of casting and transposing the weights again.  A change is
+# seen through torch's version counter of the tensor (any torch write: set_weights, load) or through `weights_written()`, which the
+# optimizer calls after its HIP update (raw-pointer writes that torch's counter cannot see).
+_OPERANDS = {}
+_GENERATION = [0]
+_OPERANDS_MAX = 512
+
+
+def weights_written():
+    """Every cached operand image is stale (called by AdamW.apply_gradients after chb_adamw has rewritten the variables)."""
+    _GENERATION[0] += 1
+    _OPERANDS.clear()
 
 
 def _weight_operands(w_kn, n_pad):
     """fp32 [K, N] master -> bf16 [N_pad, K] (forward B operand: rows = output features) and bf16 [K, N_pad] (dgrad B operand).
     Pad columns are zero.  Data movement + one rounding; runs inside Function.forward (no tape)."""
     k, n = w_kn.shape
+    key = (id(w_kn), n_pad)           # the tensor OBJECT (a variable's leaf tensor), not its address: freed memory is re-used
+    hit = _OPERANDS.get(key)
+    if hit is not None and hit[4]() is w_kn and hit[0] == w_kn._version and hit[1] == _GENERATION[0] and hit[5] == w_kn.data_ptr():
+        return hit[2], hit[3]
     wb = K.cast_bf16(w_kn.detach().contiguous())
     if n_pad != n:
         full = torch.zeros((k, n_pad), dtype=torch.bfloat16, device=w_kn.device)
-        full[:, :n] = wb
+        K.store_rows(full[:, :n], wb)
         wb = full
-    return wb.t().contiguous(), wb
+    wt = torch.empty((n_pad, k), dtype=torch.bfloat16, device=w_kn.device)
+    wt.copy_(wb.t())          # a strided device copy (data movement)
+    if len(_OPERANDS) >= _OPERANDS_MAX:
+        _OPERANDS.clear()
+    _OPERANDS[key] = (w_kn._version, _GENERATION[0], wt, wb, weakref.ref(w_kn), w_kn.data_ptr())
+    return wt, wb
 
 
 class LinearFn(torch.autograd.Function):
@@ -57,7 +87,8 @@ class LinearFn(torch.autograd.Function):
             raise ValueError("the MFMA GEMM needs in_features % 64 == 0 (got %d)" % k)
         n_pad = _pad64(n)
         lead = x.shape[:-1]
-        a_buf, a = _bf16_rows(x.detach().reshape(-1, k))
+        taped = torch.is_grad_enabled() and any(ctx.needs_input_grad[:3])
+        a_buf, a = _bf16_rows(x.detach().reshape(-1, k), pad=taped)
         m = a.shape[0]
         wt, wkn = _weight_operands(w_kn, n_pad)
         b = None
@@ -83,7 +114,8 @@ class LinearFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.x_dtype = x.dtype
         ctx.m = m
-        ctx.save_for_backward(a_buf, wkn, aux, out if act == "tanh" else None)
+        if taped:
+            ctx.save_for_backward(a_buf, wkn, aux, out if act == "tanh" else None)
         y = out if n_pad == n else out[:, :n]
         return y.reshape(*lead, n)
 
@@ -132,7 +164,8 @@ class LinearResidualFn(torch.autograd.Function):
         if k % 64 or n % 64:
             raise ValueError("the fused residual projection needs in / out features % 64 == 0 (got %d -> %d)" % (k, n))
         lead = resid.shape[:-1]
-        a_buf, a = _bf16_rows(x.detach().reshape(-1, k))
+        taped = torch.is_grad_enabled() and any(ctx.needs_input_grad[:4])
+        a_buf, a = _bf16_rows(x.detach().reshape(-1, k), pad=taped)
         m = a.shape[0]
         wt, wkn = _weight_operands(w_kn, n)
         r = resid.detach().reshape(m, n)
@@ -143,7 +176,8 @@ class LinearResidualFn(torch.autograd.Function):
                   drop_key=int(key) if rate else 0)
         ctx.rate, ctx.key, ctx.k, ctx.n, ctx.lead, ctx.x_dtype, ctx.x_lead = float(rate), int(key), k, n, lead, x.dtype, x.shape[:-1]
         ctx.r_dtype, ctx.m = resid.dtype, m
-        ctx.save_for_backward(a_buf, wkn)
+        if taped:
+            ctx.save_for_backward(a_buf, wkn)
         return out.reshape(*lead, n)
 
     @staticmethod
@@ -239,10 +273,11 @@ class AttentionGeneralFn(torch.autograd.Function):
     (Tq != Tk), through chb_attention_general_fwd / _bwd.  q [B*Tq, H*hd], k / v [B*Tk, H*hd]; masks uint8 [B, T] or None."""
 
     @staticmethod
-    def forward(ctx, q, k, v, b, tq, tk, h, hd, vmask, qmask, causal, rate, key):
+    def forward(ctx, q, k, v, b, tq, tk, h, hd, vmask, qmask, causal, rate, key, scale=0.0):
         qq, kk, vv = (K.cast_bf16(t.detach()).contiguous() for t in (q, k, v))
-        o, lse = K.attention_general_fwd(qq, kk, vv, b, tq, tk, h, hd, vmask, qmask, causal, rate, key if rate else 0)
+        o, lse = K.attention_general_fwd(qq, kk, vv, b, tq, tk, h, hd, vmask, qmask, causal, rate, key if rate else 0, scale=scale)
         ctx.dims = (b, tq, tk, h, hd, bool(causal), float(rate), int(key) if rate else 0)
+        ctx.scale = float(scale)
         ctx.dtypes = (q.dtype, k.dtype, v.dtype)
         ctx.masks = (vmask, qmask)
         ctx.save_for_backward(qq, kk, vv, o, lse)
@@ -253,9 +288,9 @@ class AttentionGeneralFn(torch.autograd.Function):
         qq, kk, vv, o, lse = ctx.saved_tensors
         b, tq, tk, h, hd, causal, rate, key = ctx.dims
         dq, dk, dv = K.attention_general_bwd(qq, kk, vv, o, K.cast_bf16(do).contiguous(), lse, b, tq, tk, h, hd, ctx.masks[0], ctx.masks[1],
-                                             causal, rate, key)
+                                             causal, rate, key, scale=ctx.scale)
         out = [K.cast_bf16(g) if dt == torch.bfloat16 else g for g, dt in zip((dq, dk, dv), ctx.dtypes)]
-        return (out[0], out[1], out[2]) + (None,) * 10
+        return (out[0], out[1], out[2]) + (None,) * 11
 
 
 class DropoutFn(torch.autograd.Function):

@@ -84,6 +84,8 @@ class AdamW:
                 with torch.no_grad():
                     var.value.copy_(pp[:n].reshape(p.shape))
         self.iterations = t
+        from .layers import autograd as _ag
+        _ag.weights_written()        # chb_adamw rewrote the variables through raw pointers: cached bf16 operand images are stale
 
     def get_config(self):
         return {"name": self.name, "learning_rate": self.learning_rate, "beta_1": self.beta_1, "beta_2": self.beta_2, "epsilon": self.epsilon,

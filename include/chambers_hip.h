@@ -194,11 +194,13 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
  * [B*Tk, H*hd] ACCUMULATED with atomics (the caller zeroes them). */
 int chb_attention_general_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
                               float* lse, int B, int Tq, int Tk, int H, int hd, const uint8_t* value_mask, const uint8_t* query_mask,
-                              int causal, float drop_rate, uint32_t drop_key, void* stream);
+                              int causal, float drop_rate, uint32_t drop_key, float scale, void* stream);
 int chb_attention_general_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
                               const void* d_o, int64_t ldg, const float* lse, float* dq, float* dk, float* dv, int B, int Tq, int Tk, int H,
                               int hd, const uint8_t* value_mask, const uint8_t* query_mask, int causal, float drop_rate, uint32_t drop_key,
-                              void* stream);
+                              float scale, void* stream);
+/* scale: the factor on the raw scores, 1 / sqrt(key_dim) when ScaledAttention was given a key_dim (layers/attention.py:8-22 divides by
+ * sqrt(key_dim) whatever the width of the tensors); <= 0 means 1 / sqrt(hd), the key_dim=None case. */
 
 /* ---------------------------------------------------------------- input side */
 #define CHB_DT_U8 0

@@ -85,3 +85,22 @@ def test_tile_queue_ticket_register_is_untouched_until_its_wait():
     assert len(found) >= 20 and not problems, problems[:5]
     src = open(os.path.join(ROOT, "chambers_amd", "engine.py")).read()
     assert 'set_option("GEMM_TILE_QUEUE"' not in src          # the engine never forces the queue on
+
+
+def test_fused_augment_kernels_hold_no_select_with_a_scalar_data_operand():
+    """the hipcc 7.2 fault behind vgpr_byte() (csrc/augment.hip) needs a per-byte select whose constant arm sits in
+    a scalar register; on the BUILT augment.o no select / byte-merge instruction of a fused_* kernel may name one
+    (tools/check_byte_select_isa.py) - a hoisted record or an unguarded new select site fails here, on the CPU tier."""
+    import importlib.util
+    import shutil
+    obj = os.path.join(ROOT, "chambers_amd", "csrc", "augment.o")
+    if not os.path.exists(obj) or not shutil.which("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the built augment.o and the ROCm llvm tools")
+    spec = importlib.util.spec_from_file_location("check_byte_select_isa", os.path.join(ROOT, "tools", "check_byte_select_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels, n_sel, bad = mod.check(mod.device_disassembly(obj))
+    assert kernels >= 50 and n_sel >= 1000 and not bad, bad[:5]
+    # the checker does see the form it is looking for
+    fake = "0000 <fused_x>:\n\tv_cndmask_b32_e32 v1, s5, v2, vcc // 0\n\tv_cndmask_b32_e64 v1, v3, v2, s[4:5] // 0\n"
+    assert len(mod.check(fake)[2]) == 1

@@ -68,6 +68,27 @@ def test_randaugment_elementwise_full_batch_512x224():
     _eq(out, A.rand_augment_elementwise(x, 2, 9, dec), "RandAugment elementwise 512x224x224")
 
 
+@pytest.mark.parametrize("shape", [(6, 40, 56, 3), (9, 64, 64, 3), (3, 224, 224, 3)])
+@pytest.mark.parametrize("second", [1, 0])          # Equalize / AutoContrast: the table ops, whose histogram pass evaluates the level below
+def test_cutout_first_chains_under_a_table_op_small_shapes(shape, second):
+    """the shape of chain the hipcc 7.2 byte-select fault corrupted (CutOut FIRST, then Equalize / AutoContrast: the
+    histogram pass counted CutOut's value for the wrong pixels, in two of three channels) - per-image route, every image its own
+    centre, at SMALL shapes; in round 3 only the 512 x 224 x 224 batch caught it.  Mixed with chains that start with another op, so
+    the sorted launches see several groups.  Bit-exact against the oracle, patch-row output included."""
+    from chambers_amd import augmentations as aug
+    b, h, w, _ = shape
+    x = _img(shape, 21 + second)
+    x[0] = (x[0] // 3) + 60
+    g = np.random.Generator(np.random.PCG64(77 + b))
+    dec = []
+    for n in range(b):
+        first = 14 if n % 3 != 2 else int(g.integers(0, 16))          # CutOut first in two of three images
+        dec.append([{"op": first, "negate": bool(g.uniform() < 0.5), "centers": np.array([[int(g.integers(0, h)), int(g.integers(0, w))]], dtype=np.int32)},
+                    {"op": second, "negate": False, "centers": np.zeros((1, 2), np.int32)}])
+    layer = aug.RandAugment(2, 9, elementwise=True)
+    _eq(layer(_dev(x), training=True, decisions=dec), A.rand_augment_elementwise(x, 2, 9, dec), "CutOut-first chains under a table op")
+
+
 def test_contrast_constant_and_signs_are_per_image():
     """What elementwise mode changes semantically: Contrast's constant is H*W/256 of ONE image
     (196 at 224x224; the batch-shared mode clips B*H*W/256 to 255), and the sign of a warp is drawn per image."""

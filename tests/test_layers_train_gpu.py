@@ -360,6 +360,27 @@ def test_scaled_attention_masks_causal_cross_attention(causal, use_masks, tq, tk
         assert not bool(out.detach()[~qmask.cuda()[:, None, :].expand(b, h, tq)].any())                # masked queries give zero rows
 
 
+@pytest.mark.parametrize("hd,key_dim,t", [(64, 16, 12), (32, 64, 9)])
+def test_scaled_attention_divides_by_sqrt_key_dim_whatever_the_tensor_width(hd, key_dim, t):
+    """the reference divides the scores by sqrt(key_dim) whenever key_dim is given (layers/attention.py:8-22), also when it
+    differs from the width of the tensors - a layer that builds and runs there must run here, with that scale (general kernel)."""
+    from chambers_amd.layers.attention import ScaledAttention
+    g = torch.Generator().manual_seed(41)
+    b, h = 2, 2
+    q = bf(torch.randn(b, h, t, hd, generator=g)).cuda().requires_grad_(True)
+    k = bf(torch.randn(b, h, t, hd, generator=g)).cuda().requires_grad_(True)
+    v = bf(torch.randn(b, h, t, hd, generator=g)).cuda().requires_grad_(True)
+    out = ScaledAttention(key_dim=key_dim)([q, v, k])
+    dy = torch.randn(out.shape, generator=g).cuda()
+    out.backward(dy.to(out.dtype))
+    qr, kr, vr = (x.detach().double().requires_grad_(True) for x in (q, k, v))
+    ref = torch.matmul(torch.softmax(torch.matmul(qr, kr.transpose(-1, -2)) / np.sqrt(key_dim), dim=-1), vr)
+    ref.backward(bf(dy).double())
+    assert rel_l2(out.detach().float(), ref.detach()) < 4e-3
+    for got, want, name in ((q.grad, qr.grad, "dq"), (k.grad, kr.grad, "dk"), (v.grad, vr.grad, "dv")):
+        assert rel_l2(got.float(), want) < 8e-3, name
+
+
 def test_multi_head_attention_cross_attention_with_masks_trains():
     """MultiHeadAttention.call(inputs=[q, v, k], mask=[query_mask, value_mask]) with different query / memory sequences
     (layers/attention.py:99-145), causal=False: output and the gradient of every weight against the einsum definition in fp64."""
