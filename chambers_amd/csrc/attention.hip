@@ -1025,14 +1025,20 @@ constexpr size_t OFF_DELTA = OFF_LSE + (size_t)RING * 256;
 constexpr size_t OFF_K = OFF_DELTA + (size_t)RING * 128;
 constexpr size_t OFF_V = OFF_K + (size_t)2 * NP * HD * 2;
 constexpr size_t OFF_DST = OFF_V + (size_t)NKT * 16 * HD * 2;
-constexpr size_t LDS_BYTES = OFF_DST + (size_t)2 * NP * 64;      // 163,328 of the CU's 163,840 bytes
+constexpr size_t OFF_HEADS = OFF_DST + (size_t)2 * NP * 64;
+constexpr size_t LDS_BYTES = OFF_HEADS + 16;                     // 163,344 of the CU's 163,840 bytes
 static_assert(LDS_BYTES <= 160 * 1024, "the pipelined attention backward needs the whole LDS of a CU, not more");
 }  // namespace pipe
+
+// head counters of the persistent kernel: one slot per launch in flight (launches of different streams never share one); a launch
+// leaves its slot at zero
+constexpr int PIPE_CTR_SLOTS = 32;
+__device__ unsigned int g_pipe_head_ctr[PIPE_CTR_SLOTS];
 
 template <bool DROP>
 __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                             const uint32_t* __restrict__ drop_bits, int N, int H, int total_heads, float scale,
+                                                             const uint32_t* __restrict__ drop_bits, unsigned int* __restrict__ head_ctr, int N, int H, int total_heads, float scale,
                                                              float scale_log2, float drop_scale, int dbg) {
     const int dbg_period = dbg & 1023;          // timing experiments (tools/attn_pipe_check.py): results are WRONG when dbg != 0
     const bool dbg_no_b = dbg & 1024, dbg_no_prod = dbg & 2048, dbg_no_acc = dbg & 4096, dbg_no_soft = dbg & 8192;
@@ -1049,13 +1055,27 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
     bf16_t* Kimg = reinterpret_cast<bf16_t*>(smem_raw + OFF_K);       // [2][NP][64]
     bf16_t* Vimg = reinterpret_cast<bf16_t*>(smem_raw + OFF_V);       // [16 NKT][64]
     char* dST = smem_raw + OFF_DST;                                    // [2][NP keys][64 bytes]
+    int* heads = reinterpret_cast<int*>(smem_raw + OFF_HEADS);   // [4]: head of the k-th turn of this workgroup at [k & 3], -1 = none (plain LDS
+                                                                 // accesses: every barrier of this kernel is a compiler memory barrier too)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int Dm = H * HD;
     const int64_t D3 = 3 * (int64_t)Dm;
-    const int nh = (total_heads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // heads of this workgroup (>= 1)
-    const int T = nh * NQB;                                                                 // its steps
+    // Heads are CLAIMED, not assigned: a workgroup draws its next head from a device counter (ticket = head index), two heads ahead of
+    // the one it is working on, so that a workgroup that starts late - its CU was held by another kernel, e.g. a collective running
+    // beside this launch - simply draws fewer heads instead of stretching the launch by its whole static share.  Wave 13 draws: two
+    // tickets in the prologue, one more at the first step of every head it has (exactly two tickets of every workgroup come back
+    // >= total_heads; the holder of the last ticket of the launch, total_heads + 2 gridDim.x - 1, puts the counter back to zero).
+    auto claim = [&]() -> int {            // wave 13, uniform: one ticket
+        unsigned t = 0;
+        if (lane == 0) {
+            t = atomicAdd(head_ctr, 1u);
+            if (t == (unsigned)total_heads + 2u * gridDim.x - 1u) atomicExch(head_ctr, 0u);
+        }
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        return t < (unsigned)total_heads ? (int)t : -1;
+    };
     const int r8 = lane >> 3, c8 = lane & 7;
 
     // one K or V image piece = 8 rows x 128 bytes (rows >= N re-read row N - 1: finite, and every use of them is masked)
@@ -1067,21 +1087,39 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
         glds16_pipe_s(sbase, voff, img + inst * 512);
     };
 
-    // ---- prologue: zero dS^T (rows of dead key tiles stay zero for good), first head's K / V, the producer's first three steps
+    // ---- prologue: the first two heads; zero dS^T (rows of dead key tiles stay zero for good); first head's K / V; the producer's first
+    // three steps
+    if (wave == 13) {
+        const int h0 = claim();
+        const int h1 = claim();
+        if (lane == 0) {
+            heads[0] = h0;
+            heads[1] = h1;
+            heads[2] = -1;
+            heads[3] = -1;
+        }
+    }
+    __syncthreads();
+    const int head0 = heads[0];
+    if (head0 < 0) return;                 // every head was taken before this workgroup started (uniform over the workgroup)
     for (int id = tid; id < 2 * NP * 4; id += 1024) reinterpret_cast<uint4*>(dST)[id] = make_uint4(0, 0, 0, 0);
     if (wave == 13) {
-        for (int inst = 0; inst < NP / 8; ++inst) kv_piece((int)blockIdx.x, 1, inst, Kimg);
+        for (int inst = 0; inst < NP / 8; ++inst) kv_piece(head0, 1, inst, Kimg);
     } else if (wave == 14) {
-        for (int inst = 0; inst < NKT * 2; ++inst) kv_piece((int)blockIdx.x, 2, inst, Vimg);
+        for (int inst = 0; inst < NKT * 2; ++inst) kv_piece(head0, 2, inst, Vimg);
     }
 
     // ---- producer pieces.  Everything the producer moves goes global -> LDS by LDS-DMA (inline asm, see glds16_pipe); delta and the
     // scaled lse of a step are formed from LDS two iterations after its pieces were issued (asm LDS reads: a DS instruction hipcc can
     // see behind a pending LDS-DMA gets a vmcnt(0) in front), so no iteration waits for a round trip to HBM it has just started.
-    auto step_head = [&](int tp, int& bh, int& q0) {       // step index -> (head, first query)
-        const int k = tp / NQB;
-        bh = (int)blockIdx.x + k * (int)gridDim.x;
+    auto step_head = [&](int tp, int& bh, int& q0) {       // step index -> (head, first query); a step past this workgroup's last head
+        const int k = tp / NQB;                            // repeats the last real step (its pieces land in slots nobody reads)
+        bh = heads[k & 3];
         q0 = 32 * (tp - k * NQB);
+        if (bh < 0) {
+            bh = heads[(k - 1) & 3];
+            q0 = 32 * (NQB - 1);
+        }
     };
     auto prod_dma = [&](int tp, int islot) {               // NDMA pieces of step tp -> ring slots of stream position islot
         int bh, q0;
@@ -1146,8 +1184,8 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
     };
     if (wave == 15) {
         prod_dma(0, 0);
-        prod_dma(min(1, T - 1), 1);
-        prod_dma(min(2, T - 1), 2);
+        prod_dma(1, 1);
+        prod_dma(2, 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1173,9 +1211,10 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
         const float4_t sinit = (float4_t){s0, s0, s0, s0};
         float4_t dk[4], dv[4];
         bf16x8_t kfr[2], vfr[2];
-        int k = 0, j = 0;
-        for (int p = 0; p <= T; ++p) {
-            if (p < T) {
+        int k = 0, j = 0, bh = head0;
+        for (int p = 0;; ++p) {
+            if (j == 0 && p) bh = heads[k & 3];
+            if (bh >= 0) {
                 if (j == 0) {
                     const bf16_t* Kc = Kimg + (k & 1) * NP * HD;
 #pragma unroll
@@ -1249,7 +1288,6 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
                 *reinterpret_cast<uint2*>(dSb + dst_w1) = make_uint2(sw.z, sw.w);
                 if (j == NQB - 1 && key < N) {
                     // the head is done for this key tile: dK^T / dV^T, lane (g,i) reg r = [d = 16dt + 4g + r][key]
-                    const int bh = (int)blockIdx.x + k * (int)gridDim.x;
                     const int b = bh / H, h = bh - b * H;
                     bf16_t* kp = dqkv + ((int64_t)b * N + key) * D3 + Dm + h * HD;
                     bf16_t* vp = kp + Dm;
@@ -1266,6 +1304,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
                 }
             }
             if (dbg_period <= 1 || p % dbg_period == 0) lds_barrier();   // dbg_period > 1: timing experiment only (results WRONG)
+            if (bh < 0) break;            // the iteration behind this workgroup's last step: phase B finishes the last block in it
             if (++j == NQB) {
                 j = 0;
                 ++k;
@@ -1287,29 +1326,35 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
             sboff[qs][0] = dst_slot(kra, qs, lpp);
             sboff[qs][1] = dst_slot(krb, qs, lpp);
         }
-        int k = 0, j = 0, pk = 0, pj = 0;
+        int k = 0, j = 0, pk = 0, pj = 0, bh = head0, pbh = -1, nxt = -1;
         bf16x8_t kt[2][NTP];
-        for (int p = 0; p <= T; ++p) {
+        for (int p = 0;; ++p) {
+            if (j == 0) {
+                if (p) bh = heads[k & 3];
+                if (bh >= 0 && wave == 13) {          // this workgroup's head after next (first read at step 1 of the next head)
+                    const int h2 = claim();
+                    if (lane == 0) heads[(k + 2) & 3] = h2;
+                }
+            }
+            if (j == 1) nxt = heads[(k + 1) & 3];     // drawn at the first step of the previous head (or in the prologue)
             // the next head's K (wave 13) / V (wave 14) pieces go out at steps 1 .. 4 of a head, 7 a step (a piece costs its issuer
             // 60 - 180 cycles: the producer alone was issue-bound); at the top of step 6 at least this wave's 8 dQ stores of steps 4
             // and 5 (blocks 3 and 4 are full for N >= 193) have been issued behind the last piece, so "at most 4 outstanding" means
             // every piece has landed - the barrier that ends step 6 publishes the images
-            if (p < T && j >= 1 && j <= 4 && k + 1 < nh && !dbg_no_prod) {
-                const int bhn = (int)blockIdx.x + (k + 1) * (int)gridDim.x;
+            if (bh >= 0 && j >= 1 && j <= 4 && nxt >= 0 && !dbg_no_prod) {
                 const int first = 7 * (j - 1);
                 if (wave == 13) {
                     bf16_t* img = Kimg + ((k + 1) & 1) * NP * HD;
 #pragma unroll
-                    for (int u = 0; u < 7; ++u) kv_piece(bhn, 1, first + u, img);                            // 28 pieces
+                    for (int u = 0; u < 7; ++u) kv_piece(nxt, 1, first + u, img);                            // 28 pieces
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 7; ++u) kv_piece(bhn, 2, min(first + u, NKT * 2 - 1), Vimg);          // 26 pieces (the last one three times)
+                    for (int u = 0; u < 7; ++u) kv_piece(nxt, 2, min(first + u, NKT * 2 - 1), Vimg);          // 26 pieces (the last one three times)
                 }
             }
-            if (p < T && j == NQB - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (bh >= 0 && j == NQB - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             if (p > 0 && !dbg_no_b) {
-                const int bh = (int)blockIdx.x + pk * (int)gridDim.x;
-                const int b = bh / H, h = bh - b * H;
+                const int b = pbh / H, h = pbh - b * H;
                 const int qb0 = 32 * pj;
                 const char* dSb = dST + ((p - 1) & 1) * NP * 64;
                 if (pj == 0) {
@@ -1357,8 +1402,10 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
                 }
             }
             if (dbg_period <= 1 || p % dbg_period == 0) lds_barrier();   // dbg_period > 1: timing experiment only (results WRONG)
+            if (bh < 0) break;
             pk = k;
             pj = j;
+            pbh = bh;
             if (++j == NQB) {
                 j = 0;
                 ++k;
@@ -1371,13 +1418,20 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
         //      in issue order): everything issued in iteration p - 2 or earlier has landed - the ring pieces of step p + 1;
         //   2. delta / scaled lse of step p + 1 from the landed pieces (published, like the pieces, by the barrier that ends step p);
         //   3. issue the ring pieces of step p + 3 (into the slots step p - 1 has just released).
-        for (int p = 0; p <= T; ++p) {
-            if (p < T && !dbg_no_prod) {
+        int k = 0, j = 0, bh = head0;
+        for (int p = 0;; ++p) {
+            if (j == 0 && p) bh = heads[k & 3];
+            if (bh >= 0 && !dbg_no_prod) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-                if (p + 1 < T) prod_aux(p + 1, p + 1);
-                prod_dma(min(p + 3, T - 1), p + 3);
+                if (j < NQB - 1 || heads[(k + 1) & 3] >= 0) prod_aux(p + 1, p + 1);       // step p + 1 exists
+                prod_dma(p + 3, p + 3);
             }
             if (dbg_period <= 1 || p % dbg_period == 0) lds_barrier();   // dbg_period > 1: timing experiment only (results WRONG)
+            if (bh < 0) break;
+            if (++j == NQB) {
+                j = 0;
+                ++k;
+            }
         }
     }
 }
@@ -1938,10 +1992,18 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
         }
         const int total = B * H;
         const dim3 pgrid(total < cus ? total : cus);
+        static std::atomic<unsigned> launch_seq{0};
+        static std::atomic<unsigned int*> ctr_of[64];           // device address of g_pipe_head_ctr, looked up once per device
+        unsigned int* ctr_base = ctr_of[dev].load(std::memory_order_acquire);
+        if (!ctr_base) {
+            if (hipGetSymbolAddress((void**)&ctr_base, HIP_SYMBOL(g_pipe_head_ctr)) != hipSuccess || !ctr_base) return CHB_ELAUNCH;
+            ctr_of[dev].store(ctr_base, std::memory_order_release);
+        }
+        unsigned int* ctr = ctr_base + launch_seq.fetch_add(1, std::memory_order_relaxed) % PIPE_CTR_SLOTS;
         if (thr) hipLaunchKernelGGL((attn_bwd_pipe_kernel<true>), pgrid, dim3(1024), pipe::LDS_BYTES, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse,
-                                    (bf16_t*)dqkv, drop_bits, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
+                                    (bf16_t*)dqkv, drop_bits, ctr, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
         else hipLaunchKernelGGL((attn_bwd_pipe_kernel<false>), pgrid, dim3(1024), pipe::LDS_BYTES, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse,
-                                (bf16_t*)dqkv, drop_bits, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
+                                (bf16_t*)dqkv, drop_bits, ctr, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
         CHB_LAUNCH_CHECK();
         return CHB_OK;
     }
