@@ -225,6 +225,8 @@ __device__ __forceinline__ uint32_t chb_pk_ge_u16(uint32_t x, uint32_t thr) {
     return d;
 }
 
+// (an inline-asm v_max3_f32 on MFMA results was tried for the row maximum and is WRONG: hipcc's hazard recognizer does not pad an asm
+// statement that reads a register an MFMA is still writing - the s_nop it places in front of ordinary consumers is missing)
 __device__ __forceinline__ void glds16_attn(const bf16_t* src, bf16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
@@ -300,8 +302,8 @@ __device__ __forceinline__ void fwd_chunk(FwdState& st, const bf16_t* Ks, const 
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl) {
             uint32_t* w = &pw[tl >> 1].x + 2 * (tl & 1);
-            w[0] &= fl[tl][0] * 0xffffu;
-            w[1] &= fl[tl][1] * 0xffffu;
+            w[0] &= __umul24(fl[tl][0], 0xffffu);       // flags at bits 0 / 16 -> 0xffff per kept half; a 24-bit multiply is full rate, a
+            w[1] &= __umul24(fl[tl][1], 0xffffu);       // 32-bit v_mul_lo_u32 a quarter of it (8 of them were 9 % of a chunk's vector cycles)
         }
         if (kc & 2) st.bits_hi |= nib4 << (4 * (kc & 1));   // wave-uniform
         else st.bits_lo |= nib4 << (4 * (kc & 1));
@@ -1436,6 +1438,150 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
     }
 }
 
+// ------------------------------------------------------------------------------------ forward, persistent pipelined kernel
+// 193 <= N <= 208, the forward counterpart of attn_bwd_pipe_kernel: one 16-wave workgroup per CU walks heads drawn from a device
+// counter.  Waves 0 .. 12 own one 16-query tile each and run exactly the chunk body of attn_fwd_head_kernel (same arithmetic, same
+// order: outputs, lse and keep bits are bit-identical); waves 13 / 14 / 15 bring the NEXT head's K / V / Q rows into the other half of
+// double-buffered LDS images by LDS-DMA (inline asm pieces, see glds16_pipe_s) while the current head is computed - the compute waves
+// issue no load at all (their Q fragments come from the Q image), only fire-and-forget stores, and meet the loaders at one LDS
+// barrier per head.  What the whole-head kernel leaves idle: its two 7-wave workgroups per CU each wait for their own K / V, then
+// for their own Q rows, before the first MFMA, and a wave carries two query tiles (14 slots for 13 tiles).
+namespace fpipe {
+constexpr int NKT = 13;
+constexpr int IMG = NKT * 16 * HD;                    // bf16 elements of one image (208 rows)
+constexpr size_t OFF_K = 0, OFF_V = OFF_K + (size_t)2 * IMG * 2, OFF_Q = OFF_V + (size_t)2 * IMG * 2, OFF_HEADS = OFF_Q + (size_t)2 * IMG * 2;
+constexpr size_t LDS_BYTES = OFF_HEADS + 16;          // 159,760 bytes
+}  // namespace fpipe
+__device__ unsigned int g_fpipe_head_ctr[32];
+
+template <bool DROP>
+__global__ void __launch_bounds__(1024, 4) attn_fwd_pipe_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse_out,
+                                                             uint32_t* __restrict__ bits_out, unsigned int* __restrict__ head_ctr, int N, int H, int total_heads,
+                                                             int Np4, float scale_log2, float drop_scale, uint32_t drop_thr, uint32_t drop_key) {
+    using namespace fpipe;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* Kimg = reinterpret_cast<bf16_t*>(smem_raw + OFF_K);
+    bf16_t* Vimg = reinterpret_cast<bf16_t*>(smem_raw + OFF_V);
+    bf16_t* Qimg = reinterpret_cast<bf16_t*>(smem_raw + OFF_Q);
+    int* heads = reinterpret_cast<int*>(smem_raw + OFF_HEADS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int Dm = H * HD;
+    const int64_t D3 = 3 * (int64_t)Dm;
+    const int r8 = lane >> 3, c8 = lane & 7;
+
+    auto claim = [&]() -> int {            // wave 13, uniform: one ticket = one head index (see attn_bwd_pipe_kernel)
+        unsigned t = 0;
+        if (lane == 0) {
+            t = atomicAdd(head_ctr, 1u);
+            if (t == (unsigned)total_heads + 2u * gridDim.x - 1u) atomicExch(head_ctr, 0u);
+        }
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        return t < (unsigned)total_heads ? (int)t : -1;
+    };
+    // the 26 pieces (8 rows x 128 bytes) of one image of head bh: which = 0 Q (swz_row), 1 K (swz_row), 2 V (swz_trv)
+    auto load_image = [&](int bh, int which, bf16_t* img) {
+        const int b = bh / H, h = bh - b * H;
+        const bf16_t* sbase = qkv + (int64_t)b * N * D3 + (int64_t)which * Dm + h * HD;
+#pragma unroll 1
+        for (int inst = 0; inst < NKT * 2; ++inst) {
+            const int r = inst * 8 + r8;
+            const int sw = which == 2 ? swz_trv(r) : swz_row(r);
+            const uint32_t voff = (__umul24((uint32_t)min(r, N - 1), (uint32_t)(3 * Dm)) + (uint32_t)((c8 ^ sw) << 3)) * 2u;
+            glds16_pipe_s(sbase, voff, img + inst * 512);
+        }
+    };
+    if (wave == 13) {
+        const int h0 = claim();
+        const int h1 = claim();
+        if (lane == 0) {
+            heads[0] = h0;
+            heads[1] = h1;
+            heads[2] = -1;
+            heads[3] = -1;
+        }
+    }
+    __syncthreads();
+    const int head0 = heads[0];
+    if (head0 < 0) return;
+    if (wave == 13) load_image(head0, 1, Kimg);
+    else if (wave == 14) load_image(head0, 2, Vimg);
+    else if (wave == 15) load_image(head0, 0, Qimg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (wave < NKT) {
+        // ================================================================ compute: query tile `wave` of every head
+        const int nkt = (N + 15) >> 4;
+        const int q = 16 * wave + i, qc = min(q, N - 1);
+        int bh = head0;
+        for (int k = 0;; ++k) {
+            if (k) bh = heads[k & 3];
+            if (bh >= 0) {
+                const bf16_t* Ks = Kimg + (k & 1) * IMG;
+                const bf16_t* Vs = Vimg + (k & 1) * IMG;
+                const bf16_t* Qs = Qimg + (k & 1) * IMG;
+                const bf16x8_t qf0 = lds_row_frag(Qs, q, g);
+                const bf16x8_t qf1 = lds_row_frag(Qs, q, 4 + g);
+                const uint32_t cbase = ((((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)Np4) >> 1) + 2u * (uint32_t)g;
+                float m_run = -INFINITY, l_run = 0.f;
+                float4_t oacc[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                uint32_t bits_lo = 0u, bits_hi = 0u;
+                const int nfull = N >> 6;
+                const int nchunk = (nkt + 3) >> 2;
+                FwdState st{m_run, l_run, oacc, bits_lo, bits_hi};
+#pragma unroll 1
+                for (int kc = 0; kc < nfull; ++kc)
+                    fwd_chunk<true, DROP>(st, Ks, Vs, qf0, qf1, kc, 4, N, g, i, cbase, scale_log2, drop_thr, drop_key);
+                if (nfull < nchunk) fwd_chunk<false, DROP>(st, Ks, Vs, qf0, qf1, nfull, nkt - 4 * nfull, N, g, i, cbase, scale_log2, drop_thr, drop_key);
+                float sum = l_run;
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float oscale = (DROP ? drop_scale : 1.0f) / sum;
+                if (q < N) {
+                    const int b = bh / H, h = bh - b * H;
+                    if (g == 0) lse_out[(int64_t)bh * N + q] = (m_run * scale_log2 + log2f(sum)) * 0.69314718055994530942f;
+                    bf16_t* op = o + ((int64_t)b * N + q) * Dm + h * HD;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        uint2 w;
+                        w.x = pack_bf16x2(oacc[dt][0] * oscale, oacc[dt][1] * oscale);
+                        w.y = pack_bf16x2(oacc[dt][2] * oscale, oacc[dt][3] * oscale);
+                        *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
+                    }
+                    if (DROP && bits_out) *reinterpret_cast<uint2*>(bits_out + (((int64_t)bh * N + q) * 4 + g) * 2) = make_uint2(bits_lo, bits_hi);
+                }
+            }
+            lds_barrier();
+            if (bh < 0) break;
+        }
+    } else {
+        // ================================================================ loaders: the next head's K (13) / V (14) / Q (15) image
+        int bh = head0;
+        for (int k = 0;; ++k) {
+            if (k) bh = heads[k & 3];
+            if (bh >= 0) {
+                if (wave == 13) {                      // this workgroup's head after next
+                    const int h2 = claim();
+                    if (lane == 0) heads[(k + 2) & 3] = h2;
+                }
+                const int nxt = heads[(k + 1) & 3];
+                if (nxt >= 0) {
+                    const int half = (k + 1) & 1;
+                    if (wave == 13) load_image(nxt, 1, Kimg + half * IMG);
+                    else if (wave == 14) load_image(nxt, 2, Vimg + half * IMG);
+                    else load_image(nxt, 0, Qimg + half * IMG);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // landed before the barrier that hands the images over
+                }
+            }
+            lds_barrier();
+            if (bh < 0) break;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ forward, long sequences
 // N > 224: the score row of a query no longer fits the register file next to K/V in LDS.  Workgroup = (head, 128
 // queries), a wave owns 16 queries; K / V stream through a double-buffered LDS chunk of 64 keys and the softmax is
@@ -1905,7 +2051,35 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
     // kernel writes them: refused.
     const bool want_bits = drop_bits != nullptr && thr != 0u;
     if (want_bits && N > 224) return CHB_EUNSUPPORTED;
-    if (N <= 224 && (want_bits || (algo != 1 && algo != 2))) {
+    // 193 <= N <= 208 (ViT at 224^2): the persistent pipelined kernel, one workgroup per CU (CHB_ATTN_FWD_ALGO = 3 keeps the
+    // whole-head kernel for A/B; 1 / 2 still force the resident / streaming kernels when no keep bits are asked for)
+    if (N >= 193 && N <= 16 * fpipe::NKT && (algo == 0 || algo == 4 || ((algo == 1 || algo == 2) && want_bits))) {
+        static std::atomic<int> n_cus[64];
+        static std::atomic<unsigned int*> ctr_of[64];
+        static std::atomic<unsigned> launch_seq{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CHB_ELAUNCH;
+        int cus = n_cus[dev].load(std::memory_order_acquire);
+        if (cus == 0) {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return CHB_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fpipe::LDS_BYTES) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fpipe::LDS_BYTES) != hipSuccess)
+                return CHB_ELAUNCH;
+            unsigned int* base = nullptr;
+            if (hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_fpipe_head_ctr)) != hipSuccess || !base) return CHB_ELAUNCH;
+            ctr_of[dev].store(base, std::memory_order_release);
+            n_cus[dev].store(cus, std::memory_order_release);
+        }
+        unsigned int* ctr = ctr_of[dev].load(std::memory_order_acquire) + launch_seq.fetch_add(1, std::memory_order_relaxed) % 32;
+        const int total = B * H;
+        const dim3 pgrid(total < cus ? total : cus);
+        const int np4 = (N + 3) & ~3;
+        if (thr) hipLaunchKernelGGL((attn_fwd_pipe_kernel<true>), pgrid, dim3(1024), fpipe::LDS_BYTES, s, in, out, lse, drop_bits, ctr, N, H, total, np4, scale_log2, ds, thr, drop_key);
+        else hipLaunchKernelGGL((attn_fwd_pipe_kernel<false>), pgrid, dim3(1024), fpipe::LDS_BYTES, s, in, out, lse, drop_bits, ctr, N, H, total, np4, scale_log2, ds, thr, drop_key);
+        CHB_LAUNCH_CHECK();
+        return CHB_OK;
+    }
+    if (N <= 224 && (want_bits || (algo != 1 && algo != 2))) {     // whole-head kernel (also algo 3: the A side of the pipelined kernel)
         const int nkt = (N + 15) >> 4;
         const int nw = (nkt + 1) >> 1;
         const size_t lds = (size_t)2 * nkt * 16 * HD * sizeof(bf16_t);

@@ -109,8 +109,8 @@ static inline int chb_div_up(long a, long b) { return (int)((a + b - 1) / b); }
 // Each switch takes its default from the environment variable CHB_<NAME> ONCE per process (first use) and can be changed at run
 // time through chb_set_option (tests and tools/ cross-check two algorithms in one process): no getenv on the launch path.
 enum ChbOption {
-    CHB_OPT_ATTN_FWD_ALGO = 0,   // 0 auto (whole-head kernel for N <= 224), 1 resident (N <= 224), 2 streaming
-    CHB_OPT_ATTN_BWD_ALGO,       // 0 auto (lean one-pass kernel unless the fused bias gradient is asked for), 1 resident 8 waves, 2 two-pass, 3 resident 16 waves, 4 = 0 without a bias gradient
+    CHB_OPT_ATTN_FWD_ALGO = 0,   // 0 auto (persistent pipelined kernel for 193 <= N <= 208, whole-head kernel for other N <= 224), 1 resident (N <= 224), 2 streaming, 3 whole-head kernel also for 193..208 (A/B)
+    CHB_OPT_ATTN_BWD_ALGO,       // 0 auto (persistent pipelined kernel for 193 <= N <= 208, else the lean one-pass kernel; the 16-wave kernel when the fused bias gradient is asked for), 1 resident 8 waves, 2 two-pass, 3 resident 16 waves, 4 lean kernel also for 193..208 (A/B), 5 = 0
     CHB_OPT_AFFINE_ALGO,         // 0 auto, 1 rows, 2 32x8 tiles, 3 16x16 tiles
     CHB_OPT_GEMM_ALGO,           // 0 auto, 1 128x128 tiles, 2 persistent 256x256, 3 persistent 128x256 x 2 workgroups / CU, 4 persistent 256x256 ping-pong (full tiles), 5 persistent 256x256 with software-pipelined fragment reads
     CHB_OPT_GEMM_WALK,           // 0 linear tile ids per XCD, 1 (default) panel walk where it pays, 2 always panel

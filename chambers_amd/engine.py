@@ -646,6 +646,15 @@ class ViTEngine:
         # C): the records are filled once - every buffer is static - and only the dropout keys (and, at inference, the ping-pong
         # x_in / x_out) change per call.  CHB_ENGINE_PY_BLOCKS=1 keeps the launch-by-launch Python path (tests compare the two).
         self.c_blocks = not bool(int(os.environ.get("CHB_ENGINE_PY_BLOCKS", "0")))
+        # Where a data-parallel run starts a block's all-reduce (C block path).  "block" (default): behind the block's last launch - the
+        # collective's workgroups then share the chip with the next block's GEMMs.  "attention": in the middle of the block, right
+        # before the attention backward (the round-3 choice, made for the lean attention kernel with its 6144 short workgroups; the
+        # persistent pipelined backward holds every CU for its whole duration, a collective started beside it is pushed behind it onto
+        # the weight-gradient GEMM, which has no tile queue: tools/rccl_contention.py measured +3.5 ms a step for it against +0.9 ... +2.4
+        # for "block"; profiles/r04_collective_contention.txt).
+        self.dp_flush = os.environ.get("CHB_DP_FLUSH", "block")
+        if self.dp_flush not in ("block", "attention"):
+            raise ValueError("CHB_DP_FLUSH must be 'block' or 'attention', got %r" % (self.dp_flush,))
         self._build_block_records()
 
     def _build_block_records(self):
@@ -969,7 +978,7 @@ class ViTEngine:
                 r = self.blocks[l]
                 r.key_attn, r.key_proj, r.key_mlp = key(rng.site_attn(l)), key(rng.site_proj(l)), key(rng.site_mlp(l))
                 r.key_prev_mlp = key(rng.site_mlp(l - 1)) if l > 0 else 0
-                if self.reducer.active:
+                if self.reducer.active and self.dp_flush == "attention":
                     # this block's MLP / projection gradients and the previous block's QKV gradients are final after phase 1 and
                     # adjacent in the flat buffer: one all-reduce, started beside the attention backward
                     _lib.call("chb_vit_block_bwd", ctypes.byref(r), 1, main_s, side_p)
@@ -977,9 +986,14 @@ class ViTEngine:
                     cjoin()           # the collective reads gradients the side stream wrote
                     self.reducer.flush()
                     _lib.call("chb_vit_block_bwd", ctypes.byref(r), 2, main_s, side_p)
+                    self.reducer.bucket_ready(2 * (L - l))
                 else:
                     _lib.call("chb_vit_block_bwd", ctypes.byref(r), 3, main_s, side_p)
-                self.reducer.bucket_ready(2 * (L - l))
+                    self.reducer.bucket_ready(2 * (L - l) - 1)
+                    self.reducer.bucket_ready(2 * (L - l))
+                    if self.reducer.active:       # dp_flush == "block": the block's whole gradient slice as one collective, started here
+                        cjoin()
+                        self.reducer.flush()
             cjoin()
         join()                    # AdamW (and the last collective) read every gradient
         # embedding stage

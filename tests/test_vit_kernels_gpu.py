@@ -640,6 +640,34 @@ def test_attention_bwd_pipelined_is_bit_identical_to_lean(bsz, n, h, rate):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.0), (2, 197, 3, 0.1), (1, 193, 1, 0.1), (3, 198, 2, 0.1), (2, 208, 2, 0.25), (23, 197, 12, 0.1),
+                                          (23, 197, 12, 0.0), (45, 200, 13, 0.1)])
+def test_attention_fwd_pipelined_is_bit_identical_to_whole_head(bsz, n, h, rate):
+    """193 <= N <= 208 runs the persistent pipelined forward (attn_fwd_pipe_kernel: heads drawn from a device counter, the next head's
+    K / V / Q images loaded by three loader waves while 13 waves compute) - the chunk body is the whole-head kernel's
+    (CHB_ATTN_FWD_ALGO = 3), so o, lse and the keep bits agree bit for bit; more heads than CUs in the last cases."""
+    from chambers_amd import _lib, kernels as K
+    d = h * 64
+    qkv = bf(torch.randn(bsz * n, 3 * d, generator=g(48)) * 1.3).cuda()
+    outs = []
+    try:
+        for algo in (3, 0):
+            _lib.set_option("ATTN_FWD_ALGO", algo)
+            o = torch.full((bsz * n, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+            lse = torch.full((bsz * h * n,), float("nan"), dtype=torch.float32, device="cuda")
+            bits = K.attention_drop_bits(bsz, n, h) if rate else None
+            if bits is not None:
+                bits.fill_(-1)
+            K.attention_fwd(qkv, o, lse, bsz, n, h, 64, rate, 0x1357, drop_bits=bits)
+            torch.cuda.synchronize()
+            outs.append((o.view(torch.int16).cpu(), lse.view(torch.int32).cpu(), None if bits is None else bits.cpu()))
+    finally:
+        _lib.set_option("ATTN_FWD_ALGO", 0)
+    a, b = outs
+    assert not torch.isnan(b[0].view(torch.bfloat16).float()).any()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and (a[2] is None or torch.equal(a[2], b[2]))
+
+
 @pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.1), (1, 224, 2, 0.0), (3, 50, 1, 0.1), (1, 1, 1, 0.0), (2, 130, 2, 0.5)])
 def test_attention_bwd_two_pass_matches_one_pass(bsz, n, h, rate, monkeypatch):
     """The long-sequence backward (N > 224) forced onto short inputs agrees with the LDS-resident one: dK / dV accumulate

@@ -73,6 +73,7 @@ def finish():
 eng.reducer.bucket_ready = bucket_ready
 eng.reducer.flush = flush
 eng.reducer.finish = finish
+eng.reducer.active = True            # the engine splits a block's backward around the flush point only for an active reducer
 
 
 def run(steps):
@@ -89,14 +90,16 @@ def run(steps):
 from chambers_amd import _lib
 
 print("batch %d  stand-in collective: %d WGs x %d us per gradient bucket (16 KiB LDS each, streaming a 21 MiB buffer)" % (batch, n_wg, micros))
-for queue in (0, 1):          # static tile shares vs the per-XCD tile queue of the persistent NT GEMM
-    _lib.set_option("GEMM_TILE_QUEUE", queue)
+for queue, attn in ((0, 0), (0, 4), (1, 0), (1, 4)):   # static tile shares vs the per-XCD tile queue of the persistent NT GEMM;
+    _lib.set_option("GEMM_TILE_QUEUE", queue)           # attention backward: persistent pipelined kernel (heads drawn from a counter) vs
+    _lib.set_option("ATTN_BWD_ALGO", attn)              # the lean kernel (one short workgroup per head)
     mode["on"] = False
     base = run(10)
     mode["on"] = True
-    print(" GEMM_TILE_QUEUE=%d   step alone %.2f ms" % (queue, base))
+    print(" GEMM_TILE_QUEUE=%d ATTN_BWD_ALGO=%d   step alone %.2f ms" % (queue, attn, base))
     for placement in ("immediate", "engine"):      # immediate: at bucket_ready (behind a persistent GEMM); engine: where the engine flushes
         mode["placement"] = placement
+        eng.dp_flush = "attention" if placement == "engine" else "block"
         launched[0] = 0
         t = run(10)
         print("   placement %-9s %2.0f launches/step   step %.2f ms   (+%.2f ms, %.1f %%)" % (placement, launched[0] / 13, t, t - base, 100 * (t / base - 1)))
