@@ -455,6 +455,8 @@ def main():
     # The host's own share of a step: one step handed over to an EMPTY queue (device idle, nothing to wait for), timed from the first
     # Python statement of the step to the return of its last launch call; median of 5.  Decisions, plans, ctypes transitions and the
     # HIP runtime's launch path, without the back-pressure of a full queue.
+    dp_counts = (red.n_collectives, red.bytes_reduced, red.exposed_ms())      # of the timed region only
+    red.measure = False
     host_single = []
     for _ in range(5):
         torch.cuda.synchronize()
@@ -540,8 +542,8 @@ def main():
             "dp": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if dist is not None else None,
                    "payload": args.grad_payload, "forced_single_rank_group": bool(args.force_dp and world == 1),
                    "world_size": dist.get_world_size() if dist is not None else 1,
-                   "allreduce_bytes_per_step": red.bytes_reduced / args.steps, "collectives_per_step": red.n_collectives / args.steps,
-                   "reducer_wait_ms_per_step": red.exposed_ms() / args.steps,
+                   "allreduce_bytes_per_step": dp_counts[1] / args.steps, "collectives_per_step": dp_counts[0] / args.steps,
+                   "reducer_wait_ms_per_step": dp_counts[2] / args.steps,
                    "ms_per_step_without_exchange": ms_no_exchange,
                    "exposed_comm_ms_per_step": (ms_per_step - ms_no_exchange) if ms_no_exchange is not None else 0.0,
                    "gradient_bytes": int(eng.G.numel() * eng.G.element_size())},

@@ -87,7 +87,7 @@ class LinearFn(torch.autograd.Function):
             raise ValueError("the MFMA GEMM needs in_features % 64 == 0 (got %d)" % k)
         n_pad = _pad64(n)
         lead = x.shape[:-1]
-        taped = torch.is_grad_enabled() and any(ctx.needs_input_grad[:3])
+        taped = any(ctx.needs_input_grad[:3])       # all False under torch.no_grad() or when nothing upstream requires grad
         a_buf, a = _bf16_rows(x.detach().reshape(-1, k), pad=taped)
         m = a.shape[0]
         wt, wkn = _weight_operands(w_kn, n_pad)
@@ -164,7 +164,7 @@ class LinearResidualFn(torch.autograd.Function):
         if k % 64 or n % 64:
             raise ValueError("the fused residual projection needs in / out features % 64 == 0 (got %d -> %d)" % (k, n))
         lead = resid.shape[:-1]
-        taped = torch.is_grad_enabled() and any(ctx.needs_input_grad[:4])
+        taped = any(ctx.needs_input_grad[:4])
         a_buf, a = _bf16_rows(x.detach().reshape(-1, k), pad=taped)
         m = a.shape[0]
         wt, wkn = _weight_operands(w_kn, n)

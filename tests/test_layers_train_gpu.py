@@ -211,6 +211,45 @@ def test_dense_is_differentiable(activation, units, m):
     assert rel_l2(x.grad, xr.grad) < tol and rel_l2(w.grad, wr.grad) < tol and rel_l2(b.grad, br.grad) < tol
 
 
+def test_dense_operand_cache_follows_every_kind_of_weight_write():
+    """ADVICE r3: repeated inference calls of a stand-alone layer re-use the bf16 images of its kernel (no tape, no padded copies);
+    the cache must notice a torch write (set_weights / copy_: the tensor's version counter), the optimizer's HIP update (raw pointers:
+    AdamW.apply_gradients calls weights_written()) and a NEW tensor that re-uses a freed one's address."""
+    from chambers_amd.layers import autograd as AG
+    from chambers_amd.layers.core import Dense
+    from chambers_amd.optimizers import AdamW
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(40, 64, generator=g).cuda()
+    layer = Dense(96)
+    layer(x)                                     # build
+    w = layer.kernel.value
+
+    def ref():
+        return (bf(x).double() @ bf(w.detach()).double() + layer.bias.value.detach().double()).float()
+
+    with torch.no_grad():
+        y1 = layer(x)
+        n_cached = len(AG._OPERANDS)
+        y2 = layer(x)
+        assert len(AG._OPERANDS) == n_cached and torch.equal(y1, y2) and rel_l2(y1, ref()) < 1e-5
+        w.copy_(torch.randn(w.shape, generator=g) * 0.1)            # torch write
+        assert rel_l2(layer(x), ref()) < 1e-5
+    xg = x.clone().requires_grad_(True)
+    layer(xg).square().mean().backward()
+    before = w.detach().clone()
+    AdamW(learning_rate=1e-2, weight_decay=0.0).apply_gradients([(None, v) for v in layer.trainable_weights])     # HIP write
+    assert not torch.equal(before, w.detach())
+    with torch.no_grad():
+        assert rel_l2(layer(x), ref()) < 1e-5
+    for _ in range(4):                           # fresh layers whose kernels may land on a freed kernel's address
+        other = Dense(96)
+        with torch.no_grad():
+            yo = other(x)
+            wo = other.kernel.value
+            assert rel_l2(yo, (bf(x).double() @ bf(wo.detach()).double() + other.bias.value.detach().double()).float()) < 1e-5
+        del other, wo, yo
+
+
 def test_layernorm_dropout_embeddings_and_gelu_are_differentiable():
     from chambers_amd import activations
     from chambers_amd.layers.core import Dropout, LayerNormalization

@@ -1,5 +1,6 @@
-"""Attention kernel timings: python tools/attn_bench.py [B N H].  Forward: whole-head (default), resident, streaming; backward:
-lean one-pass with / without the forward's keep bits (default), 16-wave and 8-wave resident, two-pass, fused bias gradient."""
+"""Attention kernel timings: python tools/attn_bench.py [B N H].  Forward: persistent pipelined (default at 193..208 tokens), whole-head,
+resident, streaming; backward: persistent pipelined (default at 193..208 tokens), lean one-pass with / without the forward's keep bits,
+16-wave and 8-wave resident, two-pass, fused bias gradient."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,7 +30,7 @@ hbm_f = (B * N * 4 * D * 2) / 1e9                     # qkv read + o written, GB
 hbm_b = (B * N * (3 * D + 2 * D + 3 * D) * 2) / 1e9   # qkv, o, do read + dqkv written
 for rate in (0.0, 0.1):
     line = "B %d N %d H %d rate %.1f\n" % (B, N, H, rate)
-    for algo, label in ((0, "head"), (1, "resident"), (2, "stream")):
+    for algo, label in ((0, "pipe (persistent, default for 193..208 tokens)"), (3, "head"), (1, "resident"), (2, "stream")):
         if (algo == 1 and N > 224):
             continue
         _lib.set_option("ATTN_FWD_ALGO", algo)
@@ -37,7 +38,8 @@ for rate in (0.0, 0.1):
         line += "   fwd[%s] %.3f ms (%.0f TF/s, %.2f TB/s algorithmic)\n" % (label, f, fl / f / 1e9, hbm_f / f)
     _lib.set_option("ATTN_FWD_ALGO", 0)
     K.attention_fwd(qkv, o, lse, B, N, H, 64, rate, 7, drop_bits=bits if rate else None)
-    for algo, label, kw in ((0, "lean + keep bits", dict(drop_bits=bits if rate else None)), (0, "lean, hashing", {}),
+    for algo, label, kw in ((0, "pipe (persistent, default for 193..208 tokens) + keep bits", dict(drop_bits=bits if rate else None)),
+                            (4, "lean + keep bits", dict(drop_bits=bits if rate else None)), (4, "lean, hashing", {}),
                             (3, "resident 16 waves", {}), (1, "resident 8 waves", {}), (2, "two-pass", {})):
         if algo in (1, 3) and N > 224:
             continue
