@@ -18,13 +18,6 @@ CHB_ATTN_BWD_ALGO=4 CHB_ATTN_FWD_ALGO=3 timeout -k 10 300 python bench.py --no-c
 timeout -k 10 300 python bench.py --no-cpu-baseline --force-dp > gpurun_out/f_dp1_fp32.json 2>/dev/null
 timeout -k 10 300 python bench.py --no-cpu-baseline --force-dp --grad-payload bf16 > gpurun_out/f_dp1_bf16.json 2>/dev/null
 CHB_GEMM_TILE_QUEUE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --force-dp > gpurun_out/f_dp1_queue.json 2>/dev/null
-timeout -k 10 200 python tools/gemm_bench.py 20 > gpurun_out/gemm_bench_final.txt 2>&1
-timeout -k 10 200 python tools/attn_bench.py > gpurun_out/attn_bench_final.txt 2>&1
-timeout -k 10 300 python tools/attn_pipe_check.py --time-only --barrier-experiment > gpurun_out/attn_pipe_ablation_final.txt 2>&1
-timeout -k 10 600 python tools/rccl_contention.py 512 32 300 > gpurun_out/contention_final.txt 2>&1
-timeout -k 10 300 python tools/augment_stage_bench.py > gpurun_out/augment_stage_final.txt 2>&1
-timeout -k 10 200 python tools/inference_latency.py 256 > gpurun_out/f_inf.txt 2>&1
 for f in f_b512 f_c4 f_c5 f_c5_nopad f_ew f_ov f_pyblocks f_oldattn f_dp1_fp32 f_dp1_bf16 f_dp1_queue; do
   python -c "import json,sys; d=json.loads(open('gpurun_out/$f.json').read().strip().splitlines()[-1]); print('$f', round(d['ms_per_step'],2), round(d['value'],1), 'host', round(d.get('host_enqueue_ms_per_step',0),2), d['roofline']['kernel'], round(d['roofline']['frac'],4), {k:round(v['tflops']) for k,v in d['roofline']['families'].items() if '256' in k}, {k: d['dp'][k] for k in ('backend','payload','collectives_per_step','reducer_wait_ms_per_step','exposed_comm_ms_per_step')})"
 done
-tail -1 gpurun_out/f_inf.txt
