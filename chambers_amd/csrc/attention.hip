@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include "../../include/chambers_hip.h"
 #include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -2023,6 +2024,26 @@ __global__ void __launch_bounds__(256) dbias_reduce_kernel(const float* __restri
     atomicAdd(dbias + c, sum);
 }
 
+
+// Head-counter slot of a persistent attention launch: one slot per (device, stream) - launches of ONE stream run one after the
+// other and each leaves its slot at zero, so they may share it; launches of different streams may overlap and never share one.  -1
+// when all slots are taken by other streams (the caller then runs the non-persistent kernel).
+static int pipe_ctr_slot(int dev, hipStream_t s) {
+    static std::mutex mu;
+    static struct { int dev; hipStream_t s; bool used; } table[32];
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < 32; ++i)
+        if (table[i].used && table[i].dev == dev && table[i].s == s) return i;
+    for (int i = 0; i < 32; ++i)
+        if (!table[i].used) {
+            table[i].used = true;
+            table[i].dev = dev;
+            table[i].s = s;
+            return i;
+        }
+    return -1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2056,7 +2077,6 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
     if (N >= 193 && N <= 16 * fpipe::NKT && (algo == 0 || algo == 4 || ((algo == 1 || algo == 2) && want_bits))) {
         static std::atomic<int> n_cus[64];
         static std::atomic<unsigned int*> ctr_of[64];
-        static std::atomic<unsigned> launch_seq{0};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CHB_ELAUNCH;
         int cus = n_cus[dev].load(std::memory_order_acquire);
@@ -2070,14 +2090,17 @@ int chb_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H,
             ctr_of[dev].store(base, std::memory_order_release);
             n_cus[dev].store(cus, std::memory_order_release);
         }
-        unsigned int* ctr = ctr_of[dev].load(std::memory_order_acquire) + launch_seq.fetch_add(1, std::memory_order_relaxed) % 32;
+        const int slot = pipe_ctr_slot(dev, s);
+        unsigned int* ctr = ctr_of[dev].load(std::memory_order_acquire) + (slot < 0 ? 0 : slot);
         const int total = B * H;
         const dim3 pgrid(total < cus ? total : cus);
         const int np4 = (N + 3) & ~3;
-        if (thr) hipLaunchKernelGGL((attn_fwd_pipe_kernel<true>), pgrid, dim3(1024), fpipe::LDS_BYTES, s, in, out, lse, drop_bits, ctr, N, H, total, np4, scale_log2, ds, thr, drop_key);
-        else hipLaunchKernelGGL((attn_fwd_pipe_kernel<false>), pgrid, dim3(1024), fpipe::LDS_BYTES, s, in, out, lse, drop_bits, ctr, N, H, total, np4, scale_log2, ds, thr, drop_key);
-        CHB_LAUNCH_CHECK();
-        return CHB_OK;
+        if (slot >= 0) {        // (none left: more than 32 streams run attention on this device - the whole-head kernel below)
+            if (thr) hipLaunchKernelGGL((attn_fwd_pipe_kernel<true>), pgrid, dim3(1024), fpipe::LDS_BYTES, s, in, out, lse, drop_bits, ctr, N, H, total, np4, scale_log2, ds, thr, drop_key);
+            else hipLaunchKernelGGL((attn_fwd_pipe_kernel<false>), pgrid, dim3(1024), fpipe::LDS_BYTES, s, in, out, lse, drop_bits, ctr, N, H, total, np4, scale_log2, ds, thr, drop_key);
+            CHB_LAUNCH_CHECK();
+            return CHB_OK;
+        }
     }
     if (N <= 224 && (want_bits || (algo != 1 && algo != 2))) {     // whole-head kernel (also algo 3: the A side of the pipelined kernel)
         const int nkt = (N + 15) >> 4;
@@ -2166,20 +2189,22 @@ int chb_attention_bwd(const void* qkv, const void* o, const void* d_o, const flo
         }
         const int total = B * H;
         const dim3 pgrid(total < cus ? total : cus);
-        static std::atomic<unsigned> launch_seq{0};
         static std::atomic<unsigned int*> ctr_of[64];           // device address of g_pipe_head_ctr, looked up once per device
         unsigned int* ctr_base = ctr_of[dev].load(std::memory_order_acquire);
         if (!ctr_base) {
             if (hipGetSymbolAddress((void**)&ctr_base, HIP_SYMBOL(g_pipe_head_ctr)) != hipSuccess || !ctr_base) return CHB_ELAUNCH;
             ctr_of[dev].store(ctr_base, std::memory_order_release);
         }
-        unsigned int* ctr = ctr_base + launch_seq.fetch_add(1, std::memory_order_relaxed) % PIPE_CTR_SLOTS;
-        if (thr) hipLaunchKernelGGL((attn_bwd_pipe_kernel<true>), pgrid, dim3(1024), pipe::LDS_BYTES, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse,
+        const int slot = pipe_ctr_slot(dev, s);
+        if (slot >= 0) {        // (none left: more than 32 streams run attention on this device - the lean kernel below)
+            unsigned int* ctr = ctr_base + slot;
+            if (thr) hipLaunchKernelGGL((attn_bwd_pipe_kernel<true>), pgrid, dim3(1024), pipe::LDS_BYTES, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse,
+                                        (bf16_t*)dqkv, drop_bits, ctr, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
+            else hipLaunchKernelGGL((attn_bwd_pipe_kernel<false>), pgrid, dim3(1024), pipe::LDS_BYTES, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse,
                                     (bf16_t*)dqkv, drop_bits, ctr, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
-        else hipLaunchKernelGGL((attn_bwd_pipe_kernel<false>), pgrid, dim3(1024), pipe::LDS_BYTES, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse,
-                                (bf16_t*)dqkv, drop_bits, ctr, N, H, total, scale, scale_log2, ds, chb_option(CHB_OPT_DEBUG));
-        CHB_LAUNCH_CHECK();
-        return CHB_OK;
+            CHB_LAUNCH_CHECK();
+            return CHB_OK;
+        }
     }
     // otherwise (no fused bias gradient): the lean kernel; it tests the forward's keep bits when they are given
     if (!dbias_qkv && (bwd_algo == 0 || bwd_algo == 4 || bwd_algo == 5)) {

@@ -668,6 +668,42 @@ def test_attention_fwd_pipelined_is_bit_identical_to_whole_head(bsz, n, h, rate)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and (a[2] is None or torch.equal(a[2], b[2]))
 
 
+def test_persistent_attention_launches_of_two_streams_do_not_share_a_head_counter():
+    """The persistent kernels draw heads from a device counter: one slot per (device, stream).  Forward + backward of two different
+    problems queued on two streams at once (several rounds, so that launches overlap in every phase) give the bytes each problem
+    gives alone."""
+    from chambers_amd import kernels as K
+    n, h = 197, 12
+    d = h * 64
+    probs = []
+    for bsz, seed in ((40, 50), (27, 60)):
+        qkv = bf(torch.randn(bsz * n, 3 * d, generator=g(seed))).cuda()
+        do = bf(torch.randn(bsz * n, d, generator=g(seed + 1))).cuda()
+        probs.append((bsz, qkv, do))
+
+    def run(bsz, qkv, do, key):
+        o = torch.empty(bsz * n, d, dtype=torch.bfloat16, device="cuda")
+        lse = torch.empty(bsz * h * n, dtype=torch.float32, device="cuda")
+        bits = K.attention_drop_bits(bsz, n, h)
+        dqkv = torch.empty(bsz * n, 3 * d, dtype=torch.bfloat16, device="cuda")
+        K.attention_fwd(qkv, o, lse, bsz, n, h, 64, 0.1, key, drop_bits=bits)
+        K.attention_bwd(qkv, o, do, lse, dqkv, bsz, n, h, 64, 0.1, key, drop_bits=bits)
+        return o, lse, dqkv
+
+    alone = [run(*p, key=0x99 + k) for k, p in enumerate(probs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _round in range(6):
+        outs = []
+        for k, p in enumerate(probs):
+            with torch.cuda.stream(streams[k]):
+                outs.append(run(*p, key=0x99 + k))
+        torch.cuda.synchronize()
+        for a, b in zip(alone, outs):
+            assert all(torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x.view(torch.int32),
+                                   y.view(torch.int16) if y.dtype == torch.bfloat16 else y.view(torch.int32)) for x, y in zip(a, b))
+
+
 @pytest.mark.parametrize("bsz,n,h,rate", [(2, 197, 3, 0.1), (1, 224, 2, 0.0), (3, 50, 1, 0.1), (1, 1, 1, 0.0), (2, 130, 2, 0.5)])
 def test_attention_bwd_two_pass_matches_one_pass(bsz, n, h, rate, monkeypatch):
     """The long-sequence backward (N > 224) forced onto short inputs agrees with the LDS-resident one: dK / dV accumulate
