@@ -260,7 +260,8 @@ __device__ __forceinline__ void fwd_chunk(FwdState& st, const bf16_t* Ks, const 
                 for (int r = 0; r < 4; ++r) s[tl][r] = (16 * t + 4 * g + r < N) ? s[tl][r] : -INFINITY;
             }
             cmax = fmaxf(cmax, fmaxf(fmaxf(s[tl][0], s[tl][1]), fmaxf(s[tl][2], s[tl][3])));
-        }
+            if (!DROP) __builtin_amdgcn_sched_barrier(0);     // without the hash work to interleave, hipcc hoists all eight K fragment reads of
+        }                                                     // a chunk in front of its first MFMA: +32 live registers, spills in the pipelined kernel
     }
     cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));

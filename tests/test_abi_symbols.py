@@ -104,3 +104,21 @@ def test_fused_augment_kernels_hold_no_select_with_a_scalar_data_operand():
     # the checker does see the form it is looking for
     fake = "0000 <fused_x>:\n\tv_cndmask_b32_e32 v1, s5, v2, vcc // 0\n\tv_cndmask_b32_e64 v1, v3, v2, s[4:5] // 0\n"
     assert len(mod.check(fake)[2]) == 1
+
+
+def test_pipelined_attention_kernels_keep_their_waits_and_m0():
+    """The persistent attention kernels (csrc/attention.hip) hand-manage m0 and every vmcnt wait; on the BUILT attention.o:
+    no m0 write outside an LDS-DMA triple, no flat / scratch access, no compiler-inserted vmcnt(0) inside a role loop
+    (tools/check_pipe_isa.py: each of these showed up during development and cost either correctness or the pipelining)."""
+    import importlib.util
+    import shutil
+    obj = os.path.join(ROOT, "chambers_amd", "csrc", "attention.o")
+    if not os.path.exists(obj) or not shutil.which("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the built attention.o and the ROCm llvm tools")
+    spec = importlib.util.spec_from_file_location("check_pipe_isa", os.path.join(ROOT, "tools", "check_pipe_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.check(mod.device_disassembly(obj))
+    assert len(res) == 4
+    for name, (problems, n_dma, _n_waits) in res.items():
+        assert not problems, (name, problems[:5])
