@@ -10,7 +10,7 @@ case $src in augment.hip|imageio.hip|elementwise.hip) extra="-ffp-contract=off";
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -munsafe-fp-atomics $extra "$@" \
     -c chambers_amd/csrc/$src -o tools/_ab/${src%.hip}_$tag.o
 objs=""
-for f in augment imageio gemm layernorm attention attention_general elementwise metric; do
+for f in augment imageio gemm layernorm attention attention_general elementwise metric vit_block; do
     if [ "$f.hip" == "$src" ]; then objs="$objs tools/_ab/${f}_$tag.o"; else objs="$objs chambers_amd/csrc/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_ab/libchambers_hip_$tag.so $objs

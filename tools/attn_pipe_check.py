@@ -5,6 +5,10 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from chambers_amd import _build
+if os.environ.get("CHB_AB_LIB"):        # A/B builds of the library (tools/ab_build.sh), this tool only
+    _build.LIB_PATH = os.path.abspath(os.environ["CHB_AB_LIB"])
+    _build.is_current = lambda: True
 from chambers_amd import _lib, kernels as K
 
 
@@ -68,7 +72,7 @@ for rate in (0.0, 0.1):
     _lib.set_option("ATTN_BWD_ALGO", 0)
     if "--barrier-experiment" in sys.argv:     # timing only, results wrong: the pipe kernel with a barrier every k-th step
         for k, what in ((1000, "no barriers"), (1024, "no phase B"), (2048, "no producer"), (4096, "no dK/dV accumulation"), (8192, "no softmax VALU"),
-                        (4096 + 8192, "no acc, no softmax"), (16384, "producer waits for pieces 3 iterations old"), (16384 + 4096 + 8192 + 1024, "that, no acc/softmax/B"), (4096 + 8192 + 1024, "producer + A's S/dP only"), (1024 + 2048, "A only"), (1024 + 2048 + 4096 + 8192, "A: S/dP MFMAs + dS store only"),
+                        (4096 + 8192, "no acc, no softmax"), (16384, "producer issues no Q pieces (10 instead of 14)"), (16384 + 4096 + 8192 + 1024, "that, no acc/softmax/B"), (4096 + 8192 + 1024, "producer + A's S/dP only"), (1024 + 2048, "A only"), (1024 + 2048 + 4096 + 8192, "A: S/dP MFMAs + dS store only"),
                         (1024 + 2048 + 4096 + 8192 + 1000, "the same without barriers")):
             _lib.set_option("DEBUG", k)
             res["pipe, " + what] = t(lambda: K.attention_bwd(qkv, o, do, lse, dqkv, B, N, H, 64, rate, 7, drop_bits=bits))
