@@ -1140,7 +1140,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_pipe_kernel(const bf16_t* __
             const int r = 8 * pc + r8;
             const uint32_t t = __umul24((uint32_t)min(r, rmax), (uint32_t)Dm);
             const uint32_t sw = (uint32_t)((c8 ^ swz_dual(r)) << 3);
-            glds16_pipe_s(qb, (3u * t + sw) * 2u, ringQ + slot * SLOT_ELEMS + pc * 512);
+            if (!(dbg & 16384)) glds16_pipe_s(qb, (3u * t + sw) * 2u, ringQ + slot * SLOT_ELEMS + pc * 512);     // (timing experiment: no Q pieces)
             glds16_pipe_s(gb, (t + sw) * 2u, ringG + slot * SLOT_ELEMS + pc * 512);
             glds16_pipe_s(ob, (t + sw) * 2u, ringO + oslot * SLOT_ELEMS + pc * 512);
         }
