@@ -48,6 +48,7 @@ PROTOTYPES = {
     "chb_gemm_tn": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P],
     "chb_gemm_tn_ws": [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, c_int, P, c_int64, c_int, P, P],
     "chb_gemm_tn_fold": [P, c_int64, P, c_int64, c_int, c_int, c_int, P],
+    "chb_gemm_tn_fold_multi": [P, c_int, P],
     "chb_layernorm_fwd": [P, c_int64, P, P, P, P, P, c_int, c_int, c_float, P],
     "chb_layernorm_bwd": [P, P, c_int64, P, P, P, P, c_int64, c_int, P, P, c_int, c_int, P, P, c_float, c_uint32, c_int, P],
     "chb_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint32, P, P],
@@ -119,7 +120,13 @@ class VitBlock(ctypes.Structure):
                                   "g_ln1_gamma", "g_ln1_beta", "g_ln2_gamma", "g_ln2_beta", "g_qkv_bias", "g_proj_bias", "g_fc1_bias",
                                   "g_prev_fc2_bias", "g_qkv_w", "g_proj_w", "g_fc1_w", "g_fc2_w", "dx", "dz", "da1", "dh", "d_o", "dqkv",
                                   "tn_ws", "tn_ws_side")] +
-                [("tn_ws_bytes", c_int64)])
+                [("tn_ws_bytes", c_int64), ("tn_ws4", P)])
+
+
+class TnFoldItem(ctypes.Structure):
+    """`chb_tn_fold_item` of include/chambers_hip.h."""
+    _fields_ = [("workspace", P), ("workspace_bytes", c_int64), ("dW", P), ("ldw", c_int64), ("M", c_int32), ("Kd", c_int32), ("Nd", c_int32),
+                ("reserved", c_int32)]
 
 
 class ProfileRecord(ctypes.Structure):

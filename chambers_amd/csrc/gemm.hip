@@ -2073,6 +2073,31 @@ __global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict_
     }
 }
 
+// the same for up to four gradients in ONE launch (a block's four weight-gradient GEMMs): block b belongs to the item whose block
+// range holds it; per item exactly tn_reduce_kernel's arithmetic (same summation order: bit-identical to four launches)
+struct FoldItem { const float* ws; float* W; int64_t ldw; int splits, Kd, Nd, first_block, blocks; };
+struct FoldBatch { FoldItem it[4]; int n; };
+__global__ void __launch_bounds__(256) tn_reduce_multi_kernel(FoldBatch fb) {
+    int k = 0;
+    while (k + 1 < fb.n && (int)blockIdx.x >= fb.it[k + 1].first_block) ++k;
+    const FoldItem f = fb.it[k];
+    const int nq = f.Nd >> 2;
+    const int64_t total = (int64_t)f.Kd * nq, plane = (int64_t)f.Kd * f.Nd;
+    for (int64_t idx = (int64_t)((int)blockIdx.x - f.first_block) * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)f.blocks * blockDim.x) {
+        const int kd = (int)(idx / nq), c = (int)(idx - (int64_t)kd * nq) * 4;
+        const float* src = f.ws + (int64_t)kd * f.Nd + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < f.splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(src + sp * plane);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(f.W + (int64_t)kd * f.ldw + c);
+        float4 w = *dst;
+        w.x += acc.x; w.y += acc.y; w.z += acc.z; w.w += acc.w;
+        *dst = w;
+    }
+}
+
 int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -2260,6 +2285,32 @@ int chb_gemm_tn_fold(const float* workspace, int64_t workspace_bytes, float* dW,
     const int64_t blocks = (quads + 255) / 256;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, workspace,
                        pl.splits, Kd, Nd, dW, ldw);
+    CHB_LAUNCH_CHECK();
+    return CHB_OK;
+}
+
+int chb_gemm_tn_fold_multi(const chb_tn_fold_item* items_host, int n_items, void* stream) {
+    if (n_items < 0 || n_items > 4 || (n_items && !items_host)) return CHB_EINVAL;
+    FoldBatch fb;
+    fb.n = 0;
+    int at = 0;
+    for (int k = 0; k < n_items; ++k) {
+        const chb_tn_fold_item& it = items_host[k];
+        if (!it.dW || it.M < 0 || it.Kd <= 0 || it.Nd <= 0) return CHB_EINVAL;
+        if (it.M == 0) continue;
+        if (it.M % 64 != 0) return CHB_EUNSUPPORTED;
+        const Tn256Plan pl = tn256_plan(it.M, it.Kd, it.Nd, it.workspace, it.workspace_bytes, it.dW, it.ldw);
+        if (!pl.planes) continue;              // that GEMM took the atomic epilogue: nothing to fold
+        const int64_t quads = (int64_t)it.Kd * (it.Nd / 4);
+        const int64_t blocks = (quads + 255) / 256;
+        FoldItem& f = fb.it[fb.n++];
+        f.ws = it.workspace; f.W = it.dW; f.ldw = it.ldw; f.splits = pl.splits; f.Kd = it.Kd; f.Nd = it.Nd;
+        f.first_block = at;
+        f.blocks = (int)(blocks < 8192 ? blocks : 8192);
+        at += f.blocks;
+    }
+    if (!fb.n) return CHB_OK;
+    hipLaunchKernelGGL(tn_reduce_multi_kernel, dim3((unsigned)at), dim3(256), 0, (hipStream_t)stream, fb);
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

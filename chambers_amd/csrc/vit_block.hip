@@ -173,10 +173,23 @@ int chb_vit_block_bwd(const chb_vit_block* b, int phases, void* stream, void* si
     }
     // weight gradient dW += X^T dY (+ column sums of dY): on the side stream when there is one - it depends only on saved activations
     // and on the operand `which` (0 dz, 1 da1, 2 dqkv) the main stream has just finished, and only the optimizer reads its output
+    // with tn_ws4 every weight gradient of the call leaves its split-K planes in a scratch of its own and ONE launch folds them at the
+    // end of the call (fold_pending); otherwise each GEMM is followed by its own fold launch
+    chb_tn_fold_item pending[4];
+    int n_pending = 0;
     auto wgrad = [&](const void* X, int64_t ldx, const void* dY, int64_t ldy, float* dW, int64_t ldw, int Kd, int Nd, float* colsum, int which) -> int {
-        if (!side_s) return chb_gemm_tn_ws(X, ldx, dY, ldy, dW, ldw, Mp, Kd, Nd, b->tn_ws, b->tn_ws_bytes, 1, colsum, stream);
+        float* ws = side_s ? b->tn_ws_side : b->tn_ws;
+        int fold = 1;
+        if (b->tn_ws4 && n_pending < 4) {
+            ws = b->tn_ws4 + (size_t)n_pending * (size_t)(b->tn_ws_bytes / 4);
+            fold = 0;
+            pending[n_pending].workspace = ws; pending[n_pending].workspace_bytes = b->tn_ws_bytes; pending[n_pending].dW = dW; pending[n_pending].ldw = ldw;
+            pending[n_pending].M = Mp; pending[n_pending].Kd = Kd; pending[n_pending].Nd = Nd; pending[n_pending].reserved = 0;
+            ++n_pending;
+        }
+        if (!side_s) return chb_gemm_tn_ws(X, ldx, dY, ldy, dW, ldw, Mp, Kd, Nd, ws, b->tn_ws_bytes, fold, colsum, stream);
         if (hipEventRecord(ev->ready[which], main_s) != hipSuccess || hipStreamWaitEvent(side_s, ev->ready[which], 0) != hipSuccess) return CHB_ELAUNCH;
-        const int rc = chb_gemm_tn_ws(X, ldx, dY, ldy, dW, ldw, Mp, Kd, Nd, b->tn_ws_side, b->tn_ws_bytes, 1, colsum, side_stream);
+        const int rc = chb_gemm_tn_ws(X, ldx, dY, ldy, dW, ldw, Mp, Kd, Nd, ws, b->tn_ws_bytes, fold, colsum, side_stream);
         if (rc != CHB_OK) return rc;
         if (hipEventRecord(ev->read[which], side_s) != hipSuccess) return CHB_ELAUNCH;
         ev->read_pending[which] = true;
@@ -220,6 +233,7 @@ int chb_vit_block_bwd(const chb_vit_block* b, int phases, void* stream, void* si
                                       stream));
         }
     }
+    if (n_pending) CHB_TRY(chb_gemm_tn_fold_multi(pending, n_pending, side_s ? side_stream : stream));
     return CHB_OK;
 }
 

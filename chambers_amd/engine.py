@@ -659,6 +659,13 @@ class ViTEngine:
 
     def _build_block_records(self):
         cfg = self.cfg
+        # CHB_FOLD_BATCH=1: one split-K scratch per weight gradient of a block, so that ONE launch folds the four
+        # (chb_gemm_tn_fold_multi): 16 fold launches a step instead of 49.  Measured and left OFF: 67.22 / 67.24 ms
+        # per step against 67.01 / 66.99 with a fold behind every GEMM (same box, alternating runs) - a fold that follows its GEMM at
+        # once finds the 66 MB of planes in the Infinity Cache; four of them at the end of the block come from HBM.
+        self.tn_ws4 = None
+        if self.training and self.c_blocks and bool(int(os.environ.get("CHB_FOLD_BATCH", "0"))):
+            self.tn_ws4 = torch.empty(4 * self.tn_ws.numel(), dtype=torch.float32, device=self.dev)
         L, d = cfg.n_encoder_layers, cfg.patch_dim
         dp = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         self.blocks = []
@@ -691,6 +698,7 @@ class ViTEngine:
                 r.d_o = dp(self.do)
                 r.tn_ws, r.tn_ws_bytes = dp(self.tn_ws), self.tn_ws.numel() * 4
                 r.tn_ws_side = dp(self.tn_ws_side) if self.overlap_wgrad else None
+                r.tn_ws4 = dp(self.tn_ws4) if self.tn_ws4 is not None else None
             self.blocks.append(r)
 
     def activation_bytes(self):

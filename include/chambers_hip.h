@@ -147,6 +147,16 @@ int chb_gemm_tn_ws(const void* X, int64_t ldx, const void* dY, int64_t ldy, floa
  * fold != 0 above folds right away; with fold == 0 the planes stay in the scratch until this call (same arguments), e.g. to
  * bracket the GEMM launch alone with events.  A no-op when the GEMM of these arguments takes the atomic epilogue. */
 int chb_gemm_tn_fold(const float* workspace, int64_t workspace_bytes, float* dW, int64_t ldw, int M, int Kd, int Nd, void* stream);
+/* Up to four such folds in ONE launch (a block's four weight gradients, each GEMM run with fold == 0 into a scratch of its own):
+ * items_host = HOST array of the arguments chb_gemm_tn_fold would get; per gradient the same sums in the same order. */
+typedef struct chb_tn_fold_item {
+    const float* workspace;
+    int64_t workspace_bytes;
+    float* dW;
+    int64_t ldw;
+    int32_t M, Kd, Nd, reserved;
+} chb_tn_fold_item;
+int chb_gemm_tn_fold_multi(const chb_tn_fold_item* items_host, int n_items, void* stream);
 
 /* keras LayerNormalization over the last axis (layers/transformer.py:39,49,283): x fp32 rows at
  * stride x_stride, y bf16 [M,D]; mean/rstd fp32 [M] saved for backward. D % 4 == 0, D <= 1024. */
@@ -459,6 +469,8 @@ typedef struct chb_vit_block {
     void *dz, *da1, *dh, *d_o, *dqkv;       /* bf16 scratch [Mp,D], [Mp,FF], [Mp,D], [Mp,D], [Mp,3D]; dz in / out */
     float *tn_ws, *tn_ws_side;              /* split-K scratch of the weight-gradient GEMMs (chb_gemm_tn_ws), tn_ws_bytes each */
     int64_t tn_ws_bytes;
+    float* tn_ws4;                          /* optional: 4 x tn_ws_bytes - one scratch per weight gradient of the block, folded by ONE launch per
+                                               chb_vit_block_bwd call (chb_gemm_tn_fold_multi) instead of one per GEMM; NULL: fold per GEMM */
 } chb_vit_block;
 int chb_vit_block_fwd(const chb_vit_block* block_host, int training, void* stream);
 int chb_vit_block_bwd(const chb_vit_block* block_host, int phases, void* stream, void* side_stream);

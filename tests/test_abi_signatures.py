@@ -71,7 +71,7 @@ def _struct_fields(name):
     return fields
 
 
-@pytest.mark.parametrize("cname,pyname", [("chb_vit_block", "VitBlock"), ("chb_profile_record", "ProfileRecord")])
+@pytest.mark.parametrize("cname,pyname", [("chb_vit_block", "VitBlock"), ("chb_profile_record", "ProfileRecord"), ("chb_tn_fold_item", "TnFoldItem")])
 def test_struct_mirrors_match_the_header(cname, pyname, tmp_path):
     from chambers_amd import _lib
     py = getattr(_lib, pyname)
