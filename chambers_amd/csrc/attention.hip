@@ -685,6 +685,16 @@ __device__ __forceinline__ void keep4(uint32_t e0, uint32_t drop_key, uint32_t d
     for (int r = 0; r < 4; ++r) out[r] = ((odd ? uo[r] : ue[r]) >= drop_thr) ? drop_scale : 0.f;
 }
 
+// the same for an EVEN e0 (row stride and key offset both multiples of 4): two hashes, no parity select
+__device__ __forceinline__ void keep4_even(uint32_t e0, uint32_t drop_key, uint32_t drop_thr, float drop_scale, float out[4]) {
+    const uint32_t c0 = e0 >> 1;
+    const uint32_t h0 = chb_hash32(c0 ^ drop_key), h1 = chb_hash32((c0 + 1u) ^ drop_key);
+    out[0] = ((h0 & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
+    out[1] = ((h0 >> 16) >= drop_thr) ? drop_scale : 0.f;
+    out[2] = ((h1 & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
+    out[3] = ((h1 >> 16) >= drop_thr) ? drop_scale : 0.f;
+}
+
 __device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
     const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
     float d = 0.f;
@@ -1814,6 +1824,25 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __re
                     sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag_dual(Qs, 16 * qs + i, 4 * ks + g), kfr[ks], sv, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag_dual(Gs, 16 * qs + i, 4 * ks + g), vfr[ks], dp, 0, 0, 0);
                 }
+                // keys i and i^1 of one query share a hash word (the row stride is even): the even lane hashes queries r = 0, 1, the
+                // odd lane r = 2, 3, and a quad_perm [1,0,3,2] hands each the other's two
+                uint32_t hw[4];
+                if (DROP) {
+                    uint32_t hm[2], ho[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ql = 16 * qs + 4 * g + 2 * (i & 1) + j;
+                        const uint32_t e = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + ql, N - 1)) * (uint32_t)((N + 3) & ~3) + (uint32_t)min(key, N - 1);
+                        hm[j] = chb_hash32((e >> 1) ^ drop_key);
+                        ho[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm[j], 0xB1, 0xF, 0xF, true);
+                    }
+                    const bool odd_lane = (i & 1) != 0;
+                    hw[0] = odd_lane ? ho[0] : hm[0];
+                    hw[1] = odd_lane ? ho[1] : hm[1];
+                    hw[2] = odd_lane ? hm[0] : ho[0];
+                    hw[3] = odd_lane ? hm[1] : ho[1];
+                }
+                const bool key_odd = (min(key, N - 1) & 1) != 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ql = 16 * qs + 4 * g + r;
@@ -1821,9 +1850,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(const bf16_t* __re
                     if (!tile_full) p = (key < N) ? p : 0.f;
                     float keepc = 1.0f;
                     if (DROP) {
-                        const uint32_t e = ((uint32_t)bh * (uint32_t)N + (uint32_t)min(q0 + ql, N - 1)) * (uint32_t)((N + 3) & ~3) + (uint32_t)min(key, N - 1);
-                        const uint32_t hsh = chb_hash32((e >> 1) ^ drop_key);
-                        const uint32_t u = (e & 1u) ? (hsh >> 16) : (hsh & 0xffffu);
+                        const uint32_t u = key_odd ? (hw[r] >> 16) : (hw[r] & 0xffffu);
                         keepc = (u >= drop_thr) ? drop_scale : 0.f;
                     }
                     pd[qs][r] = p * keepc;
@@ -1965,7 +1992,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(const bf16_t* __res
                             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag_dual(Vs, 16 * t + i, 4 * ks + g), gb[ks], dp, 0, 0, 0);
                         }
                         float keepc[4] = {1.f, 1.f, 1.f, 1.f};
-                        if (DROP) keep4(ebase + (uint32_t)key0, drop_key, drop_thr, drop_scale, keepc);
+                        if (DROP) keep4_even(ebase + (uint32_t)key0, drop_key, drop_thr, drop_scale, keepc);   // ebase, key0: multiples of 4
                         const bool tile_full = k0 + 16 * t + 16 <= N;   // wave-uniform
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
