@@ -126,6 +126,13 @@ class Layer:
 
     trainable_weights = weights
 
+    def named_weights(self, scope=""):
+        """[(name as Keras scopes it - 'encoder/encoder_layer/dense1/kernel:0' - , Variable)] in the order of `weights`."""
+        out = [(scope + v.name, v) for v in self._weights]
+        for sub in self._sublayers():
+            out.extend(sub.named_weights(scope + self.name + "/"))
+        return out
+
     def get_weights(self):
         return [w.numpy() for w in self.weights]
 

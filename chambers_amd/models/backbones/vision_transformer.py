@@ -257,6 +257,15 @@ class Model(Layer):
         self.assign_keras_weights(timm_state_dict_to_keras(state_dict, self.cfg.n_heads, include_top=self.cfg.include_top))
 
     def save_weights(self, path):
+        """keras Model.save_weights: a path ending in `.h5` / `.hdf5` gets Keras' own HDF5 weight-file layout (what the reference's
+        checkpoint callbacks write, callbacks.py:31-38,99,103; written by chambers_amd.utils.hdf5_lite, readable by h5py / Keras and
+        by load_weights here); any other path an `.npz` of Keras-named arrays."""
+        path = str(path)
+        if path.endswith((".h5", ".hdf5")):
+            from ...utils.hdf5_lite import save_keras_weights
+            self._sync()
+            save_keras_weights(path, [(l.name, [(n, v.numpy()) for n, v in l.named_weights()]) for l in self._layers])
+            return
         np.savez(path, **self.keras_weights())
 
     # ---- execution

@@ -1,4 +1,5 @@
-"""A small pure-Python reader for the subset of HDF5 that Keras weight files use (no h5py / libhdf5 in this image).
+"""A small pure-Python reader AND writer for the subset of HDF5 that Keras weight files use (no h5py / libhdf5 in this image's
+test interpreter).
 
 The reference loads pretrained ViT weights with `model.load_weights(path_to.h5)` (models/backbones/vision_transformer.py:149-169);
 Keras writes such files through h5py with the library defaults, i.e. the "earliest" file-format features:
@@ -9,6 +10,10 @@ Keras writes such files through h5py with the library defaults, i.e. the "earlie
 Exactly that subset is implemented, from the HDF5 File Format Specification (version 2.0); anything else (chunked or filtered
 datasets, version-2 object headers / dense groups, variable-length data) raises NotImplementedError naming the feature.
 Validated against files written by h5py 3.3 / libhdf5 1.10.6 (tests/golden/keras_weights_*.h5, made by tests/golden/make_h5_golden.py).
+The writer (`save_keras_weights`, bottom of the file) emits the same "earliest" structures - superblock 0, version-1 object headers in
+one block, symbol-table groups (local heap, SNOD leaves of 8, B-tree nodes of 32, as many levels as the links need), contiguous
+datasets, fixed-length string attributes - and is checked the other way round: h5py / libhdf5 reads what it wrote
+(tests/golden/check_h5_with_h5py.py, run by tests/test_hdf5_lite.py in the image's conda interpreter).
 """
 import numpy as np
 
@@ -373,3 +378,183 @@ def load_keras_weights(path):
         for name in wn:
             out[name] = np.asarray(g[name][()], dtype=np.float32)
     return out, layout
+
+
+# ---- writer: the same subset, for `Model.save_weights(path.h5)` -------------------------------------------------------------------
+_LEAF_K, _NODE_K = 4, 16          # libhdf5's defaults (superblock fields): 8 symbols per SNOD, 32 children per B-tree node
+_KERAS_ATTR_LIMIT = 64512         # keras HDF5_OBJECT_HEADER_LIMIT: longer name lists are split into name0, name1, ...
+
+
+def _u(v, n):
+    return int(v).to_bytes(n, "little")
+
+
+def _dtype_message(dt):
+    """Datatype message body (version 1) of a little-endian IEEE float / two's-complement integer, or ('S', n) fixed-length bytes."""
+    if isinstance(dt, tuple):
+        return bytes([0x13, 0x01, 0, 0]) + _u(dt[1], 4)                                     # string, null-padded, ASCII
+    dt = np.dtype(dt)
+    if dt.kind == "f" and dt.itemsize in (2, 4, 8):
+        exp_bits, man_bits = {2: (5, 10), 4: (8, 23), 8: (11, 52)}[dt.itemsize]
+        bits = 8 * dt.itemsize
+        return (bytes([0x11, 0x20, bits - 1, 0]) + _u(dt.itemsize, 4) + _u(0, 2) + _u(bits, 2)
+                + bytes([man_bits, exp_bits, 0, man_bits]) + _u((1 << (exp_bits - 1)) - 1, 4))
+    if dt.kind in "iu" and dt.itemsize in (1, 2, 4, 8):
+        return bytes([0x10, 0x08 if dt.kind == "i" else 0x00, 0, 0]) + _u(dt.itemsize, 4) + _u(0, 2) + _u(8 * dt.itemsize, 2)
+    raise NotImplementedError("writing HDF5 datatype %s" % dt)
+
+
+def _dataspace_message(shape):
+    return bytes([1, len(shape), 0, 0, 0, 0, 0, 0]) + b"".join(_u(s, 8) for s in shape)      # version 1, no maximum dimensions
+
+
+def _padded(b):
+    return b + bytes(-len(b) % 8)
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(96)                                   # superblock (version 0) + root symbol-table entry, filled by close()
+
+    def put(self, data):
+        self.buf.extend(bytes(-len(self.buf) % 8))
+        addr = len(self.buf)
+        self.buf.extend(data)
+        return addr
+
+    def header(self, messages):
+        """Version-1 object header in one block: messages = [(type, flags, body)]."""
+        body = b"".join(_u(t, 2) + _u(len(_padded(m)), 2) + bytes([fl, 0, 0, 0]) + _padded(m) for t, fl, m in messages)
+        for _t, _fl, m in messages:
+            if len(m) > 0xFFF8:
+                raise Hdf5Error("object header message of %d bytes (limit 65528)" % len(m))
+        return self.put(bytes([1, 0]) + _u(len(messages), 2) + _u(1, 4) + _u(len(body), 4) + bytes(4) + body)
+
+    def attribute(self, name, value):
+        """Attribute message (version 1): bytes -> fixed-length scalar string; list of bytes -> 1-D fixed-length string array;
+        numpy array / scalar -> numeric."""
+        nm = name.encode() + b"\x00"
+        if isinstance(value, (bytes, str)):
+            value = value.encode() if isinstance(value, str) else value
+            dt, ds, data = _dtype_message(("S", max(len(value), 1))), _dataspace_message(()), value.ljust(max(len(value), 1), b"\x00")
+        elif isinstance(value, (list, tuple)) or (isinstance(value, np.ndarray) and value.dtype.kind == "S"):
+            items = [v.encode() if isinstance(v, str) else bytes(v) for v in value]
+            width = max([len(v) for v in items] + [1])
+            dt, ds, data = _dtype_message(("S", width)), _dataspace_message((len(items),)), b"".join(v.ljust(width, b"\x00") for v in items)
+        else:
+            arr = np.asarray(value, order="C")                   # (ascontiguousarray would make a scalar 1-D)
+            arr = arr.astype(arr.dtype.newbyteorder("<"), copy=False)
+            dt, ds, data = _dtype_message(arr.dtype), _dataspace_message(arr.shape), arr.tobytes()
+        return (0x000C, 0, bytes([1, 0]) + _u(len(nm), 2) + _u(len(dt), 2) + _u(len(ds), 2) + _padded(nm) + _padded(dt) + _padded(ds) + data)
+
+    def dataset(self, array):
+        arr = np.asarray(array, order="C")
+        arr = arr.astype(arr.dtype.newbyteorder("<"), copy=False)
+        raw = arr.tobytes()
+        addr = self.put(raw) if raw else UNDEF
+        return self.header([(0x0001, 0, _dataspace_message(arr.shape)), (0x0003, 1, _dtype_message(arr.dtype)),
+                            (0x0005, 1, bytes([2, 2, 2, 1]) + _u(0, 4)),                  # fill value v2: late allocation, written if set, size 0
+                            (0x0008, 0, bytes([3, 1]) + _u(addr, 8) + _u(len(raw), 8))])  # layout v3, contiguous
+
+    def group(self, links, attrs=()):
+        """links: {name: object header address}; attrs: [(name, value)].  -> (header address, B-tree address, heap address)."""
+        names = sorted(links, key=lambda s: s.encode())
+        heap_data = bytearray(8)                                   # offset 0: the empty string every group B-tree's first key points at
+        offs = {}
+        for n in names:
+            offs[n] = len(heap_data)
+            heap_data.extend(_padded(n.encode() + b"\x00"))
+        data_addr = self.put(bytes(heap_data))
+        heap = self.put(b"HEAP" + bytes(4) + _u(len(heap_data), 8) + _u(1, 8) + _u(data_addr, 8))    # free list: none (H5HL_FREE_NULL)
+        # leaves: symbol nodes of up to 8 entries; (address, heap offset of the largest name below)
+        level = []
+        for i in range(0, len(names), 2 * _LEAF_K):
+            part = names[i:i + 2 * _LEAF_K]
+            ents = b"".join(_u(offs[n], 8) + _u(links[n], 8) + bytes(24) for n in part)
+            level.append((self.put(b"SNOD" + bytes([1, 0]) + _u(len(part), 2) + ents + bytes(40 * (2 * _LEAF_K - len(part)))), offs[part[-1]]))
+        depth = 0
+        while True:
+            nodes = []
+            groups = [level[i:i + 2 * _NODE_K] for i in range(0, len(level), 2 * _NODE_K)] or [[]]
+            size = 24 + 8 * (2 * _NODE_K + 1) + 8 * 2 * _NODE_K
+            base = self.put(bytes(0))                               # the nodes of one level lie back to back: sibling addresses are known
+            first_key = 0
+            for j, kids in enumerate(groups):
+                left = base + size * (j - 1) if j else UNDEF
+                right = base + size * (j + 1) if j + 1 < len(groups) else UNDEF
+                body = b"TREE" + bytes([0, depth]) + _u(len(kids), 2) + _u(left, 8) + _u(right, 8) + _u(first_key, 8)
+                for addr, key in kids:
+                    body += _u(addr, 8) + _u(key, 8)
+                a = self.put(body.ljust(size, b"\x00"))
+                assert a == base + size * j
+                last = kids[-1][1] if kids else 0
+                nodes.append((a, last))
+                first_key = last
+            if len(nodes) == 1:
+                btree = nodes[0][0]
+                break
+            level, depth = nodes, depth + 1
+        msgs = [(0x0011, 0, _u(btree, 8) + _u(heap, 8))] + [self.attribute(k, v) for k, v in attrs]
+        return self.header(msgs), btree, heap
+
+    def close(self, root):
+        hdr, btree, heap = root
+        self.buf.extend(bytes(-len(self.buf) % 8))
+        sb = (_SIG + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + _u(_LEAF_K, 2) + _u(_NODE_K, 2) + _u(0, 4)
+              + _u(0, 8) + _u(UNDEF, 8) + _u(len(self.buf), 8) + _u(UNDEF, 8)
+              + _u(0, 8) + _u(hdr, 8) + _u(1, 4) + _u(0, 4) + _u(btree, 8) + _u(heap, 8))
+        assert len(sb) == 96
+        self.buf[:96] = sb
+        return bytes(self.buf)
+
+
+def _name_list_attrs(key, names):
+    """keras save_attributes_to_hdf5_group: one attribute, or key0, key1, ... so that each stays under the object-header limit."""
+    items = [n.encode("utf8") for n in names]
+    for n in items:
+        if len(n) > _KERAS_ATTR_LIMIT:
+            raise RuntimeError("The following attribute cannot be saved to HDF5 file because it is larger than %d bytes: %r" % (_KERAS_ATTR_LIMIT, n))
+    chunks = 1
+    split = [items]
+    while any(len(c) * max([len(v) for v in c] + [1]) > _KERAS_ATTR_LIMIT for c in split):
+        chunks += 1
+        split = [list(c) for c in np.array_split(np.asarray(items, dtype=object), chunks)]
+    if chunks == 1:
+        return [(key, items)]
+    return [("%s%d" % (key, i), c) for i, c in enumerate(split)]
+
+
+def save_keras_weights(path, layers, backend="tensorflow", keras_version="2.6.0"):
+    """Write what keras `Model.save_weights(path.h5)` writes (hdf5_format.save_weights_to_hdf5_group; the reference's checkpoints,
+    callbacks.py:31-38,99,103): root attributes `layer_names`, `backend`, `keras_version`; one group per layer with attribute
+    `weight_names`; one dataset per weight under its variable name, whose '/' make nested groups.
+    layers = [(layer name, [(weight name, array)])], in model order."""
+    w = _Writer()
+
+    def build(tree, attrs):
+        links = {}
+        for name, node in tree.items():
+            links[name] = build(node, [])[0] if isinstance(node, dict) else w.dataset(node)
+        return w.group(links, attrs)
+
+    top = {}
+    for lname, weights in layers:
+        if lname in top or "/" in lname:
+            raise ValueError("layer name %r: duplicate, or contains '/'" % lname)
+        tree = {}
+        for wname, arr in weights:
+            parts = [p for p in wname.split("/") if p]
+            node = tree
+            for p in parts[:-1]:
+                node = node.setdefault(p, {})
+                if not isinstance(node, dict):
+                    raise ValueError("weight name %r runs through the dataset %r" % (wname, p))
+            if parts[-1] in node:
+                raise ValueError("duplicate weight name %r in layer %r" % (wname, lname))
+            node[parts[-1]] = np.asarray(arr)
+        top[lname] = (tree, _name_list_attrs("weight_names", [n for n, _ in weights]))
+    links = {lname: build(tree, attrs)[0] for lname, (tree, attrs) in top.items()}
+    root = w.group(links, _name_list_attrs("layer_names", [l for l, _ in layers])
+                   + [("backend", backend.encode()), ("keras_version", keras_version.encode())])
+    with open(path, "wb") as fh:
+        fh.write(w.close(root))
