@@ -675,17 +675,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attn_bwd_kernel(const bf16_t*
 //                    walks the key chunks (K / V double-buffered in LDS); scores are recomputed transposed
 //                    (S^T = K.Q^T) so dS^T feeds the dQ MFMA straight from the accumulators.
 
-// dropout keep factors for 4 consecutive elements e0 .. e0+3 (three hashes cover the 16-bit halves of both parities)
-__device__ __forceinline__ void keep4(uint32_t e0, uint32_t drop_key, uint32_t drop_thr, float drop_scale, float out[4]) {
-    const uint32_t c0 = e0 >> 1, odd = e0 & 1u;
-    const uint32_t h0 = chb_hash32(c0 ^ drop_key), h1 = chb_hash32((c0 + 1u) ^ drop_key), h2 = chb_hash32((c0 + 2u) ^ drop_key);
-    const uint32_t ue[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
-    const uint32_t uo[4] = {h0 >> 16, h1 & 0xffffu, h1 >> 16, h2 & 0xffffu};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = ((odd ? uo[r] : ue[r]) >= drop_thr) ? drop_scale : 0.f;
-}
-
-// the same for an EVEN e0 (row stride and key offset both multiples of 4): two hashes, no parity select
+// dropout keep factors for 4 consecutive elements e0 .. e0+3, e0 EVEN (row stride and key offset are multiples of 4): the 16-bit
+// halves of two hashes
 __device__ __forceinline__ void keep4_even(uint32_t e0, uint32_t drop_key, uint32_t drop_thr, float drop_scale, float out[4]) {
     const uint32_t c0 = e0 >> 1;
     const uint32_t h0 = chb_hash32(c0 ^ drop_key), h1 = chb_hash32((c0 + 1u) ^ drop_key);
@@ -1692,7 +1683,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_stream_kernel(const bf16_t* _
                 }
                 if (DROP) {
                     float keepc[4];
-                    keep4(ebase + (uint32_t)(k0 + 16 * t + 4 * g), drop_key, drop_thr, 1.0f, keepc);
+                    keep4_even(ebase + (uint32_t)(k0 + 16 * t + 4 * g), drop_key, drop_thr, 1.0f, keepc);   // ebase, key offset: multiples of 4
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s[t][r] *= keepc[r];
                 }

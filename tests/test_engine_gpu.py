@@ -572,3 +572,55 @@ def test_ragged_token_count_runs_on_padded_tiles_and_pad_rows_stay_zero():
     assert torch.isfinite(l2).all()
     e.backward()
     assert not bool(e.dqkv[e.M:].any()) and not bool(e.da1[e.M:].any())
+
+
+def test_per_bucket_adamw_inside_backward_equals_the_one_launch_update():
+    """train_step applies AdamW (and refreshes the bf16 operand images) bucket by bucket from inside backward, on a stream of its
+    own, as soon as a bucket's gradients are final (engine.py `_bucket_ready`).  Same gradient in, the bucket-wise update and the
+    one launch over the flat buffer leave master weights, both moments and both operand images BIT-identical, and every gradient
+    element cleared (the buckets cover the whole buffer); a few training steps either way reach the same loss."""
+    from chambers_amd.engine import ViTConfig, ViTEngine, init_keras_weights
+    cfg = ViTConfig(patch_size=16, patch_dim=256, n_encoder_layers=3, n_heads=4, ff_dim=1024, image_size=(96, 96), classes=16, dropout_rate=0.1)
+    kw = init_keras_weights(cfg, seed=5)
+    g = np.random.Generator(np.random.PCG64(21))
+    labels = torch.as_tensor(g.integers(0, 16, size=(32,)).astype(np.int32), device="cuda")
+    images = torch.as_tensor(g.integers(0, 256, size=(32, 96, 96, 3), dtype=np.uint8), device="cuda")
+    eng = ViTEngine(cfg, 32, training=True, seed=3)
+    eng.load_keras_weights(kw)
+    eng.early_adamw = True        # (opt-in: CHB_EARLY_ADAMW=1)
+    eng.train_step(images, labels, learning_rate=1e-3, weight_decay=0.05)      # non-trivial moments
+    eng.forward(images, training=True)
+    eng.loss(labels)
+    eng.backward()
+    torch.cuda.synchronize()
+    state0 = [t.clone() for t in (eng.P, eng.Mo, eng.Vo, eng.G)]
+    step0 = eng.opt_step
+    eng.adamw_step(learning_rate=1e-3, weight_decay=0.05)
+    torch.cuda.synchronize()
+    late = [t.clone() for t in (eng.P, eng.Mo, eng.Vo, eng.Pb, eng.Pbt, eng.G)]
+    for dst, src in zip((eng.P, eng.Mo, eng.Vo, eng.G), state0):
+        dst.copy_(src)
+    eng.Pb.fill_(0); eng.Pbt.fill_(0)
+    eng.opt_step = step0 + 1
+    eng.opt_stream = eng.opt_stream or torch.cuda.Stream()
+    eng._early_hp = (eng._lr_t(1e-3, 0.9, 0.999, eng.opt_step), 0.9, 0.999, 1e-7, 0.05)
+    for k in range(len(eng.buckets)):
+        eng._bucket_ready(k)
+    eng._early_hp = None
+    torch.cuda.synchronize()
+    early = (eng.P, eng.Mo, eng.Vo, eng.Pb, eng.Pbt, eng.G)
+    for name, a, b in zip(("P", "m", "v", "Pb", "Pbt", "G"), late, early):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a.view(torch.int16),
+                           b.view(torch.int32) if b.dtype == torch.float32 else b.view(torch.int16)), name
+    assert float(late[0].sub(state0[0]).abs().max()) > 0 and int(torch.count_nonzero(eng.G)) == 0
+    losses = []
+    for early_on in (True, False):
+        e2 = ViTEngine(cfg, 32, training=True, seed=3)
+        e2.early_adamw = early_on
+        e2.load_keras_weights(kw)
+        for _ in range(4):
+            loss = e2.train_step(images, labels, learning_rate=1e-3, weight_decay=0.05)
+        torch.cuda.synchronize()
+        assert (e2.opt_stream is not None) is early_on and e2.opt_step == 4
+        losses.append(float(loss.float().mean()))
+    assert abs(losses[0] - losses[1]) < 2e-3 * abs(losses[1]), losses
