@@ -117,6 +117,7 @@ enum ChbOption {
     CHB_OPT_TN_ATOMICS,          // 1 = always the atomic epilogue
     CHB_OPT_TN_FAST,             // 0 = generic staging addresses everywhere (default 1)
     CHB_OPT_GEMM_TILE_QUEUE,     // 1 = persistent NT GEMM workgroups claim their tiles after the first from per-XCD counters (the engine turns it on when it trains data-parallel), 0 (default) = static tile shares
+    CHB_OPT_LN_STREAM,           // LayerNorm: 1 = x / dy / the old dx are read with non-temporal loads (they are not read again before they leave the caches), 0 = plain loads
     CHB_OPT_DEBUG,               // timing experiments only (tools/): e.g. 1 = attention backward without its main loop; results are WRONG
     CHB_OPT_COUNT
 };

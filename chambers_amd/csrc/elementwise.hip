@@ -17,7 +17,7 @@ namespace {
 struct OptionDef { const char* name; int dflt; };
 const OptionDef kOptions[CHB_OPT_COUNT] = {
     {"ATTN_FWD_ALGO", 0}, {"ATTN_BWD_ALGO", 0}, {"AFFINE_ALGO", 0}, {"GEMM_ALGO", 0}, {"GEMM_WALK", 1}, {"TN_ATOMICS", 0}, {"TN_FAST", 1},
-    {"GEMM_TILE_QUEUE", 0}, {"DEBUG", 0},
+    {"GEMM_TILE_QUEUE", 0}, {"LN_STREAM", 0}, {"DEBUG", 0},
 };
 std::atomic<int> g_option[CHB_OPT_COUNT];
 std::atomic<bool> g_option_read[CHB_OPT_COUNT];

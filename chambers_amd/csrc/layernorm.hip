@@ -10,7 +10,29 @@
 
 namespace {
 
-template <int NCH>
+// Streaming loads (CHB_LN_STREAM, NT): x, dy and the old dx are read once here and not again before they have left the caches;
+// a non-temporal load does not allocate them on the way in, so it does not push out what the producer GEMM left there
+// (tools/ln_bench.py, profiles/r04_layernorm_stream_ab.txt).  A/B builds: -DCHB_LN_BLOCKS=<n> caps the backward grid,
+// -DCHB_LN_NO_TAIL drops the dgamma / dbeta / column-sum atomics (timing only).
+template <bool NT>
+__device__ __forceinline__ float4 ln_load(const float4* p) {
+    if (!NT) return *p;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool NT>
+__device__ __forceinline__ uint2 ln_load(const uint2* p) {
+    if (!NT) return *p;
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p));
+    return make_uint2(v.x, v.y);
+}
+#ifndef CHB_LN_BLOCKS
+#define CHB_LN_BLOCKS 1024
+#endif
+
+template <int NCH, bool NT>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, int64_t x_stride, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D,
@@ -25,7 +47,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = lane + 64 * j;
-            v[j] = (c < nchunk) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[j] = (c < nchunk) ? ln_load<NT>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
         const float mean = wave_sum(s) * inv_d;
@@ -61,7 +83,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += dy*xhat; dbeta += dy.
-template <int NCH>
+template <int NCH, bool NT>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, float* __restrict__ dx, int64_t dx_stride,
@@ -93,8 +115,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
         for (int j = 0; j < NCH; ++j) {
             const int c = lane + 64 * j;
             if (c < nchunk) {
-                const float4 xv = xr[c];
-                const uint2 dv = dyr[c];
+                const float4 xv = ln_load<NT>(xr + c);
+                const uint2 dv = ln_load<NT>(dyr + c);
                 const float d0 = bf16_to_f32((bf16_t)(dv.x & 0xffff)), d1 = bf16_to_f32((bf16_t)(dv.x >> 16));
                 const float d2 = bf16_to_f32((bf16_t)(dv.y & 0xffff)), d3 = bf16_to_f32((bf16_t)(dv.y >> 16));
                 xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
@@ -120,7 +142,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
                 float4 o = make_float4(rstd * (gy[j].x - c1 - xh[j].x * c2), rstd * (gy[j].y - c1 - xh[j].y * c2),
                                        rstd * (gy[j].z - c1 - xh[j].z * c2), rstd * (gy[j].w - c1 - xh[j].w * c2));
                 if (accumulate) {
-                    const float4 p = dxr[c];
+                    const float4 p = ln_load<NT>(dxr + c);
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 dxr[c] = o;
@@ -165,6 +187,9 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
             }
         }
     }
+#ifdef CHB_LN_NO_TAIL
+    if (M >= 0) return;
+#endif
     // block-level reduce of dgamma/dbeta partials over the 4 waves, then one atomic per column
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -205,12 +230,19 @@ int chb_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, cons
     const dim3 grid(ln_grid(M)), block(256);
     hipStream_t s = (hipStream_t)stream;
     bf16_t* yo = (bf16_t*)y;
+    const bool nt = chb_option(CHB_OPT_LN_STREAM) != 0;
+#define LN_FWD(NCH)                                                                                                              \
+    do {                                                                                                                         \
+        if (nt) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true>), grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps);  \
+        else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps);    \
+    } while (0)
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps); break;
-        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps); break;
-        case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps); break;
-        default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, x_stride, gamma, beta, yo, mean, rstd, M, D, eps); break;
+        case 1: LN_FWD(1); break;
+        case 2: LN_FWD(2); break;
+        case 3: LN_FWD(3); break;
+        default: LN_FWD(4); break;
     }
+#undef LN_FWD
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }
@@ -231,16 +263,23 @@ int chb_layernorm_bwd(const void* dy, const float* x, int64_t x_stride, const fl
     if (M == 0) return CHB_OK;
     const int nch = (D / 4 + 63) / 64;
     int blocks = (M + 3) / 4;
-    if (blocks > 1024 || (zero_gaps && dx_stride > D)) blocks = 1024;    // the gap fill wants the whole chip
+    if (blocks > CHB_LN_BLOCKS || (zero_gaps && dx_stride > D)) blocks = CHB_LN_BLOCKS;    // the gap fill wants the whole chip
     const dim3 grid(blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* d = (const bf16_t*)dy;
+    const bool nt = chb_option(CHB_OPT_LN_STREAM) != 0;
+#define LN_BWD(NCH)                                                                                                              \
+    do {                                                                                                                         \
+        if (nt) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps);  \
+        else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); \
+    } while (0)
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); break;
-        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); break;
-        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, d, x, x_stride, mean, rstd, gamma, dx, dx_stride, accumulate, dgamma, dbeta, M, D, dz, dz_colsum, dscale, dthr, drop_key, zero_gaps); break;
+        case 1: LN_BWD(1); break;
+        case 2: LN_BWD(2); break;
+        case 3: LN_BWD(3); break;
+        default: LN_BWD(4); break;
     }
+#undef LN_BWD
     CHB_LAUNCH_CHECK();
     return CHB_OK;
 }

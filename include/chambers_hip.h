@@ -379,7 +379,7 @@ int chb_aug_fused_items_sorted(const uint8_t* in, void* out, int B, int H, int W
 int64_t chb_aug_fused_workspace_ints(int B, int H, int W, int n_tables);
 
 /* Tuning / A-B switch `name` (ATTN_FWD_ALGO, ATTN_BWD_ALGO, AFFINE_ALGO, GEMM_ALGO, GEMM_WALK, TN_ATOMICS, TN_FAST,
- * GEMM_TILE_QUEUE; csrc/common.hpp) := value.  Defaults come from the environment variables CHB_<name>, read once per
+ * GEMM_TILE_QUEUE, LN_STREAM; csrc/common.hpp) := value.  Defaults come from the environment variables CHB_<name>, read once per
  * process; nothing on the launch path calls getenv.  Results are identical under every setting (the parity tests
  * cross-check them); only speed changes. */
 int chb_set_option(const char* name, int value);
