@@ -136,6 +136,8 @@ int chb_vit_block_fwd(const chb_vit_block* b, int training, void* stream) {
     return CHB_OK;
 }
 
+}  // extern "C"
+
 // Events of the side stream (weight gradients beside the dgrad chain): created once per process, timing off.
 namespace {
 struct SideEvents {
@@ -158,6 +160,8 @@ SideEvents& side_events() {
     return ev;
 }
 }  // namespace
+
+extern "C" {
 
 int chb_vit_block_bwd(const chb_vit_block* b, int phases, void* stream, void* side_stream) {
     if (!block_args_ok(b) || !(phases & 3)) return CHB_EINVAL;
